@@ -1,0 +1,182 @@
+/* p2aes.h -- C ABI of the MI355X-native Plonky2 proving backend for the 0xPARC/plonky2-aes gadget circuits.
+ *
+ * This is the drop-in boundary.  The reference calls the third-party `plonky2` crate
+ * through five kinds of call sites; each group of entry points below replaces one of them:
+ *
+ *   reference call site (file:line)                                          entry points here
+ *   ---------------------------------------------------------------------    --------------------------------
+ *   CircuitBuilder::<F,D>::new(config) + builder methods                     p2_builder_*
+ *     aes-gcm/src/circuit_aes.rs:178,182,186,193,249,250,300,317,334,356,357
+ *     aes-gcm/src/circuit_gcm.rs:163,314,323,339,342,356,361-364,396,403,415,423,424
+ *   gadget constructors (AesGcmTarget::build etc.)                           p2_aes_*, p2_gcm_*
+ *     aes-gcm/src/circuit_gcm.rs:49-172, aes-gcm/src/circuit_aes.rs:76-275
+ *   builder.build::<PoseidonGoldilocksConfig>()                              p2_builder_build -> blob,
+ *     aes-gcm/src/circuit_gcm.rs:771, examples/aes_gcm_128.rs:46 (19 sites)  p2_circuit_load (GPU preprocessing)
+ *   PartialWitness::new / pw.set_target / data.prove(pw)   ** HOT PATH **    p2_prove_batch
+ *     aes-gcm/src/circuit_aes.rs:283, circuit_gcm.rs:779-781 (20 sites)
+ *   data.verify(proof)                                                       p2_verify
+ *     aes-gcm/src/circuit_gcm.rs:782 (19 sites)
+ *   native_gcm::encrypt (witness values)  aes-gcm/src/native_gcm.rs:16       p2_native_aes_gcm_encrypt
+ *
+ * Conventions: plain pointers and sizes only; every function that can fail returns 0 on success and a
+ * non-zero code otherwise, with a thread-local message available from p2_last_error().  The caller owns
+ * every buffer it passes in; the library owns handles and all device memory.  Nothing here touches the CPU
+ * oracle under oracle/: proving runs on the GPU or fails with P2_ERR_NO_DEVICE.
+ */
+#ifndef P2AES_H
+#define P2AES_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    P2_OK = 0,
+    P2_ERR_INVALID = 1,   /* bad argument / malformed blob or proof */
+    P2_ERR_NO_DEVICE = 2, /* no usable HIP device: proving has no CPU fallback */
+    P2_ERR_HIP = 3,       /* a HIP runtime call failed */
+    P2_ERR_VERIFY = 4     /* proof rejected (reason in p2_last_error) */
+};
+/* per-proof status written by p2_prove_batch (mirrors `data.prove(pw)` returning Err, circuit_aes.rs:403-405) */
+enum {
+    P2_PROOF_OK = 0,
+    P2_PROOF_WITNESS_CONFLICT = 1, /* generator output conflicts with a pre-set target, or lookup input not in table */
+    P2_PROOF_MISSING_INPUT = 2,    /* some generator never ran: an input target was not set */
+    P2_PROOF_ZETA_IN_SUBGROUP = 3  /* "Opening point is in the subgroup." */
+};
+
+const char* p2_last_error(void);
+
+/* ------------------------------------------------------------------ CircuitBuilder (host) */
+typedef struct p2_builder p2_builder;
+/* Targets are opaque 64-bit handles (virtual target index, or a routed wire). */
+typedef uint64_t p2_target;
+
+p2_builder* p2_builder_new(void); /* CircuitConfig::standard_recursion_config() */
+void p2_builder_free(p2_builder*);
+p2_target p2_builder_add_virtual_target(p2_builder*);
+p2_target p2_builder_constant(p2_builder*, uint64_t c);
+p2_target p2_builder_zero(p2_builder*);
+p2_target p2_builder_one(p2_builder*);
+/* c0*m0*m1 + c1*addend */
+p2_target p2_builder_arithmetic(p2_builder*, uint64_t c0, uint64_t c1, p2_target m0, p2_target m1, p2_target addend);
+p2_target p2_builder_mul_const_add(p2_builder*, uint64_t c, p2_target x, p2_target y); /* c*x + y */
+p2_target p2_builder_add(p2_builder*, p2_target x, p2_target y);
+p2_target p2_builder_sub(p2_builder*, p2_target x, p2_target y);
+p2_target p2_builder_mul(p2_builder*, p2_target x, p2_target y);
+p2_target p2_builder_select(p2_builder*, p2_target b, p2_target x, p2_target y); /* if b {x} else {y} */
+p2_target p2_builder_is_equal(p2_builder*, p2_target x, p2_target y);
+void p2_builder_connect(p2_builder*, p2_target x, p2_target y);
+/* pairs = n_pairs * (input u16, output u16); returns the LUT index (an identical table is re-used) */
+size_t p2_builder_add_lookup_table_from_pairs(p2_builder*, const uint16_t* pairs, size_t n_pairs);
+/* returns the looked-up output target; (size_t)-1 lut index is an error -> returns UINT64_MAX */
+p2_target p2_builder_add_lookup_from_index(p2_builder*, p2_target looking_in, size_t lut_index);
+size_t p2_builder_num_gates(const p2_builder*);
+/* Compile the circuit.  On success *blob points to a library-owned buffer (release with p2_blob_free). */
+int p2_builder_build(p2_builder*, uint8_t** blob, size_t* blob_len);
+void p2_blob_free(uint8_t* blob);
+
+/* ------------------------------------------------------------------ AES / GCM gadgets (host) */
+size_t p2_aes_sbox_lut(p2_builder*);
+size_t p2_aes_byte_xor_lut(p2_builder*);
+size_t p2_aes_gf_2_8_mul_lut(p2_builder*);
+size_t p2_gcm_u8_unit_right_shift_lut(p2_builder*);
+size_t p2_gcm_u8_bitref_lut(p2_builder*);
+p2_target p2_aes_add_virtual_byte_target(p2_builder*, size_t u8_table_idx);
+p2_target p2_aes_add_virtual_byte_target_unsafe(p2_builder*);
+/* States are 16 targets, element [4*i + j] = row i, column j (StateTarget.0[i][j]). */
+void p2_aes_state_sub_bytes(p2_builder*, size_t sbox_lut, const p2_target* s, p2_target* out);
+void p2_aes_state_mix_columns(p2_builder*, size_t xor_lut, size_t mul_lut, const p2_target* s, p2_target* out);
+p2_target p2_aes_gf_2_8_mul(p2_builder*, size_t mul_lut, p2_target x, p2_target y);
+p2_target p2_aes_gf_2_8_add(p2_builder*, size_t xor_lut, p2_target x, p2_target y);
+/* key: 4*nk bytes targets; out: 4*(nr+1) words * 4 targets, word-major */
+void p2_aes_key_expansion(p2_builder*, int nk, int nr, size_t xor_lut, size_t sbox_lut, const p2_target* key, p2_target* out);
+void p2_aes_encrypt_block(p2_builder*, int nr, size_t xor_lut, size_t mul_lut, size_t sbox_lut, const p2_target* state,
+                          const p2_target* expanded_key, p2_target* out_state);
+void p2_gcm_gctr(p2_builder*, int nr, size_t xor_lut, size_t mul_lut, size_t sbox_lut, const p2_target* expanded_key,
+                 const p2_target* icb, const p2_target* x, size_t len, p2_target* y);
+void p2_gcm_right_shift_one(p2_builder*, size_t shift_lut, const p2_target* v, p2_target* out);
+void p2_gcm_inc32(p2_builder*, const p2_target* block, p2_target* out);
+void p2_gcm_gf_2_128_mul(p2_builder*, size_t xor_lut, size_t shift_lut, size_t bitref_lut, const p2_target* x,
+                         const p2_target* y, p2_target* out);
+int p2_gcm_ghash(p2_builder*, size_t xor_lut, size_t shift_lut, size_t bitref_lut, const p2_target* h, const p2_target* x,
+                 size_t len, p2_target* out);
+/* AesGcmTarget<NK,4,NR,L,TAG>::build.  Outputs: key[4*nk], nonce[12], pt[L], ct[L], tag[16]. */
+int p2_aes_gcm_build(p2_builder*, int nk, int nr, size_t L, int with_tag, p2_target* key, p2_target* nonce, p2_target* pt,
+                     p2_target* ct, p2_target* tag);
+
+/* ------------------------------------------------------------------ native cipher (host; witness values) */
+uint8_t p2_native_gf_2_8_mul(uint8_t a, uint8_t b);
+void p2_native_aes_key_expansion(const uint8_t* key, int nk, int nr, uint8_t* out /* 16*(nr+1) */);
+void p2_native_aes_encrypt_block(const uint8_t* key, int nk, int nr, const uint8_t* in16, uint8_t* out16);
+void p2_native_gf_2_128_mul(const uint8_t* x16, const uint8_t* y16, uint8_t* out16);
+void p2_native_ghash(const uint8_t* h16, const uint8_t* x, size_t len, uint8_t* out16);
+void p2_native_gctr(const uint8_t* key, int nk, int nr, const uint8_t* icb16, const uint8_t* x, size_t len, uint8_t* y);
+void p2_native_aes_gcm_encrypt(const uint8_t* key, int nk, int nr, const uint8_t* nonce12, const uint8_t* pt, size_t len,
+                               uint8_t* ct, uint8_t* tag16);
+
+/* ------------------------------------------------------------------ circuit info / verification (host) */
+/* Shape of a compiled circuit without touching a device. */
+typedef struct {
+    uint32_t degree_bits, num_wires, num_routed_wires, num_constants_cols, num_zs_cols, num_quotient_cols, num_luts,
+        num_ops, num_levels, num_slots, num_virtual_targets, num_fri_rounds;
+    uint64_t proof_bytes; /* exact serialised proof size */
+} p2_circuit_info;
+int p2_blob_info(const uint8_t* blob, size_t len, p2_circuit_info* out);
+/* verifier_data = constants_sigmas_cap (16 digests) || circuit_digest, 68 u64 -- from p2_circuit_verifier_data */
+int p2_verify(const uint8_t* blob, size_t blob_len, const uint64_t* verifier_data, size_t verifier_data_len,
+              const uint8_t* proof, size_t proof_len);
+
+/* ------------------------------------------------------------------ GPU prover */
+typedef struct p2_circuit p2_circuit;
+/* Uploads the compiled circuit to HIP device `device` and commits constants+sigmas there (one-time). */
+p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device);
+void p2_circuit_free(p2_circuit*);
+int p2_circuit_verifier_data(const p2_circuit*, uint64_t* out, size_t cap, size_t* n_written);
+size_t p2_circuit_proof_bytes(const p2_circuit*);
+/* One PartialWitness: (target, value) pairs, values canonical (< p). */
+typedef struct {
+    const p2_target* targets;
+    const uint64_t* values;
+    size_t count;
+} p2_assignment;
+/* Proves `batch` independent witnesses of one circuit.  proofs: batch * p2_circuit_proof_bytes() bytes.
+ * status[i] receives a P2_PROOF_* code; a failed proof leaves its slot zeroed.  The call returns after the
+ * proofs are in host memory.  Safe to call concurrently on different p2_circuit handles. */
+int p2_prove_batch(p2_circuit*, size_t batch, const p2_assignment* inputs, uint8_t* proofs, int* status);
+/* Same pipeline with inputs already resident on the device and proofs left on the device:
+ * d_values: [batch][n_targets] u64 (device pointer), targets shared by the whole batch (host pointer).
+ * d_proofs: device buffer of batch * proof_bytes; d_status: device int[batch].  Asynchronous on `stream`
+ * (a hipStream_t passed as void*, NULL = the circuit's own stream); used by bench.py's timed region. */
+int p2_prove_batch_device(p2_circuit*, size_t batch, const p2_target* targets, size_t n_targets, const uint64_t* d_values,
+                          uint8_t* d_proofs, int* d_status, void* stream);
+int p2_circuit_synchronize(p2_circuit*);
+/* Per-kernel timing of the most recent batch (HIP events on the proving stream). */
+typedef struct {
+    char name[48];
+    float ms;       /* total over launches */
+    uint32_t count; /* launches */
+} p2_kernel_time;
+int p2_circuit_set_timing(p2_circuit*, int enable);
+size_t p2_circuit_get_timing(p2_circuit*, p2_kernel_time* out, size_t cap);
+
+/* ------------------------------------------------------------------ GPU primitives (parity tests / microbench) */
+int p2_gpu_device_count(void);
+/* data: n_perm * 12 u64 on host; permuted in place on the device */
+int p2_gpu_poseidon(uint64_t* states, size_t n_perm, int device);
+/* columns: [cols][n] coefficients (host) -> lde [cols][n<<rate_bits], bit-reversed index order (host) */
+int p2_gpu_lde(const uint64_t* coeffs, size_t cols, int degree_bits, int rate_bits, uint64_t* lde, int device);
+/* values [cols][n] -> coefficients [cols][n] */
+int p2_gpu_intt(const uint64_t* values, size_t cols, int degree_bits, uint64_t* coeffs, int device);
+/* column-major leaves [cols][num_leaves] -> cap digests (2^cap_height * 4 u64) */
+int p2_gpu_merkle_cap(const uint64_t* cols_major, size_t cols, size_t num_leaves, int cap_height, uint64_t* cap, int device);
+/* debug: copy a named intermediate buffer of proof `index` of the last batch to the host
+ * ("wires", "wires_cap", "zs", "zs_cap", "quotient_coeffs", "quotient_cap", "challenges", "openings", ...) */
+int p2_circuit_debug_read(p2_circuit*, const char* name, size_t index, uint64_t* out, size_t cap, size_t* n_written);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

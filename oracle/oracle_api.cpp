@@ -1,0 +1,135 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle_field.h header).  C entry points for ctypes: tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg are the only permitted callers.
+#include <omp.h>
+
+#include "oracle_aes.h"
+#include "oracle_prover.h"
+
+using namespace orc;
+
+struct Handle {
+    OCircuit* c;
+    Trace trace;
+    std::string err;
+};
+
+extern "C" {
+
+void* orc_circuit_load(const void* blob, size_t len) {
+    try {
+        Handle* h = new Handle();
+        h->c = load_circuit(blob, len);
+        return h;
+    } catch (std::exception& e) {
+        fprintf(stderr, "orc_circuit_load: %s\n", e.what());
+        return nullptr;
+    }
+}
+void orc_circuit_free(void* hp) {
+    Handle* h = (Handle*)hp;
+    if (!h) return;
+    delete h->c;
+    delete h;
+}
+uint32_t orc_degree_bits(void* hp) { return ((Handle*)hp)->c->degree_bits; }
+// verifier-only data: constants_sigmas_cap (2^cap_height digests) followed by circuit_digest; returns #u64
+size_t orc_verifier_data(void* hp, uint64_t* out, size_t cap) {
+    Handle* h = (Handle*)hp;
+    std::vector<u64> v;
+    for (auto& d : h->c->pre.tree.cap())
+        for (int i = 0; i < 4; i++) v.push_back(d.e[i]);
+    for (int i = 0; i < 4; i++) v.push_back(h->c->circuit_digest.e[i]);
+    if (out && cap >= v.size()) memcpy(out, v.data(), v.size() * 8);
+    return v.size();
+}
+// status: 0 ok, 1 witness conflict / lookup miss, 2 missing input, 3 zeta in subgroup, -1 buffer too small
+int orc_prove(void* hp, const uint64_t* targets, const uint64_t* values, size_t n_in, uint8_t* out, size_t out_cap, size_t* out_len, int want_trace) {
+    Handle* h = (Handle*)hp;
+    std::vector<uint8_t> proof;
+    h->trace.clear();
+    int st = prove(*h->c, targets, values, n_in, proof, want_trace ? &h->trace : nullptr);
+    if (st) return st;
+    *out_len = proof.size();
+    if (proof.size() > out_cap) return -1;
+    memcpy(out, proof.data(), proof.size());
+    return 0;
+}
+size_t orc_trace_len(void* hp, const char* name) {
+    Handle* h = (Handle*)hp;
+    auto it = h->trace.find(name);
+    return it == h->trace.end() ? 0 : it->second.size();
+}
+size_t orc_trace_get(void* hp, const char* name, uint64_t* out, size_t cap) {
+    Handle* h = (Handle*)hp;
+    auto it = h->trace.find(name);
+    if (it == h->trace.end()) return 0;
+    size_t k = std::min(cap, it->second.size());
+    memcpy(out, it->second.data(), k * 8);
+    return k;
+}
+// witness only: wires [num_wires][n] column-major
+int orc_generate_witness(void* hp, const uint64_t* targets, const uint64_t* values, size_t n_in, uint64_t* wires_out) {
+    Handle* h = (Handle*)hp;
+    std::vector<std::vector<u64>> w;
+    int st = generate_witness(*h->c, targets, values, n_in, w);
+    if (st) return st;
+    for (size_t c = 0; c < w.size(); c++) memcpy(wires_out + c * h->c->n, w[c].data(), h->c->n * 8);
+    return 0;
+}
+
+// ---- primitives for unit parity
+uint64_t orc_fmul(uint64_t a, uint64_t b) { return fmul(a, b); }
+uint64_t orc_fadd(uint64_t a, uint64_t b) { return fadd(a, b); }
+uint64_t orc_fsub(uint64_t a, uint64_t b) { return fsub(a, b); }
+uint64_t orc_finv(uint64_t a) { return finv(a); }
+void orc_poseidon(uint64_t* st) { poseidon_permute(st); }
+void orc_hash_no_pad(const uint64_t* in, size_t n, uint64_t* out4) {
+    Digest d = hash_no_pad(in, n);
+    memcpy(out4, d.e, 32);
+}
+void orc_two_to_one(const uint64_t* l, const uint64_t* r, uint64_t* out4) {
+    Digest a, b;
+    memcpy(a.e, l, 32);
+    memcpy(b.e, r, 32);
+    Digest d = compress(a, b);
+    memcpy(out4, d.e, 32);
+}
+void orc_fft(uint64_t* a, int bits, int inverse) { fft_inplace(a, bits, inverse != 0); }
+// LDE of one polynomial: coeffs[n] -> values on g*<w_{n<<rate}> written in BIT-REVERSED index order
+void orc_lde(const uint64_t* coeffs, int bits, int rate_bits, uint64_t* out) {
+    std::vector<u64> c(coeffs, coeffs + ((size_t)1 << bits));
+    auto v = coset_fft(c, bits + rate_bits, GENERATOR);
+    for (size_t i = 0; i < v.size(); i++) out[rev_bits(i, bits + rate_bits)] = v[i];
+}
+// Merkle cap over row-major leaves; returns number of digests written
+size_t orc_merkle_cap(const uint64_t* leaves, size_t num_leaves, size_t width, int cap_height, uint64_t* out) {
+    MerkleTree t = build_merkle(leaves, num_leaves, width, cap_height);
+    size_t k = 0;
+    for (auto& d : t.cap())
+        for (int i = 0; i < 4; i++) out[k++] = d.e[i];
+    return t.cap().size();
+}
+// ---- AES restatement
+uint8_t orc_gf_2_8_mul(uint8_t a, uint8_t b) { return orc_aes::gmul(a, b); }
+uint8_t orc_sbox(uint8_t x) { return orc_aes::tables().S[x]; }
+// out must hold 16*(nk+7) bytes
+void orc_aes_expand_key(const uint8_t* key, int nk, uint8_t* out) {
+    auto rk = orc_aes::expand_key(key, nk);
+    memcpy(out, rk.data(), rk.size());
+}
+void orc_aes_encrypt_block(const uint8_t* key, int nk, const uint8_t* in, uint8_t* out) {
+    auto rk = orc_aes::expand_key(key, nk);
+    orc_aes::encrypt_block(rk.data(), nk + 6, in, out);
+}
+void orc_gf_2_128_mul(const uint8_t* x, const uint8_t* y, uint8_t* out) { orc_aes::gf128_mul(x, y, out); }
+void orc_ghash(const uint8_t* h, const uint8_t* x, size_t len, uint8_t* out) { orc_aes::ghash(h, x, len, out); }
+void orc_gctr(const uint8_t* key, int nk, const uint8_t* icb, const uint8_t* x, size_t len, uint8_t* y) {
+    auto rk = orc_aes::expand_key(key, nk);
+    orc_aes::gctr(rk.data(), nk + 6, icb, x, len, y);
+}
+void orc_gcm_encrypt(const uint8_t* key, int nk, const uint8_t* iv, const uint8_t* pt, size_t len, uint8_t* ct, uint8_t* tag) {
+    orc_aes::gcm_encrypt(key, nk, iv, pt, len, ct, tag);
+}
+int orc_num_threads() { return omp_get_max_threads(); }
+void orc_set_num_threads(int t) { omp_set_num_threads(t); }
+}

@@ -1,0 +1,410 @@
+"""Host-side mirror of the reference's operator interface over the C ABI (include/p2aes.h).
+
+Same names and argument meaning as the Rust call sites so the parity tests read like the reference's tests:
+
+    builder = CircuitBuilder()                                  # CircuitBuilder::<F, D>::new(config)
+    t = AesGcmTarget.build(builder, nk=4, nr=10, L=13, tag=False)   # aes-gcm/src/circuit_gcm.rs:49
+    data = builder.build()                                      # builder.build::<PoseidonGoldilocksConfig>()
+    pw = PartialWitness()                                       # PartialWitness::<F>::new()
+    t.set_targets(pw, key, nonce, pt, ct, tag)                  # circuit_gcm.rs:174
+    proof = data.prove(pw)                                      # data.prove(pw)?   (GPU; raises ProveError)
+    data.verify(proof)                                          # data.verify(proof)
+
+PyTorch is not needed here; `prove_batch_device` accepts raw device pointers (e.g. torch tensors' data_ptr()).
+"""
+import ctypes as C
+import os
+
+P = 0xFFFFFFFF00000001
+
+
+class P2Error(RuntimeError):
+    pass
+
+
+class ProveError(P2Error):
+    """`data.prove(pw)` returned Err (witness conflict, lookup miss, missing input)."""
+
+    def __init__(self, status):
+        self.status = status
+        super().__init__({1: "witness conflict or lookup input not in table", 2: "a generator never ran (missing input)",
+                          3: "opening point is in the subgroup"}.get(status, "prove failed (%d)" % status))
+
+
+def lib_path():
+    return os.environ.get("P2AES_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libp2aes.so")
+
+
+_lib = None
+u64, u8p, u64p, u16p, sz = C.c_uint64, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint16), C.c_size_t
+
+
+class _Info(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("degree_bits", "num_wires", "num_routed_wires", "num_constants_cols", "num_zs_cols",
+                                           "num_quotient_cols", "num_luts", "num_ops", "num_levels", "num_slots",
+                                           "num_virtual_targets", "num_fri_rounds")] + [("proof_bytes", C.c_uint64)]
+
+
+class _Assignment(C.Structure):
+    _fields_ = [("targets", u64p), ("values", u64p), ("count", sz)]
+
+
+class _KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("ms", C.c_float), ("count", C.c_uint32)]
+
+
+def lib():
+    """Load the shared library; fails loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise P2Error("native library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    sig = {
+        "p2_last_error": (C.c_char_p, []),
+        "p2_builder_new": (vp, []), "p2_builder_free": (None, [vp]),
+        "p2_builder_add_virtual_target": (u64, [vp]), "p2_builder_constant": (u64, [vp, u64]),
+        "p2_builder_zero": (u64, [vp]), "p2_builder_one": (u64, [vp]),
+        "p2_builder_arithmetic": (u64, [vp, u64, u64, u64, u64, u64]),
+        "p2_builder_mul_const_add": (u64, [vp, u64, u64, u64]),
+        "p2_builder_add": (u64, [vp, u64, u64]), "p2_builder_sub": (u64, [vp, u64, u64]), "p2_builder_mul": (u64, [vp, u64, u64]),
+        "p2_builder_select": (u64, [vp, u64, u64, u64]), "p2_builder_is_equal": (u64, [vp, u64, u64]),
+        "p2_builder_connect": (None, [vp, u64, u64]),
+        "p2_builder_add_lookup_table_from_pairs": (sz, [vp, u16p, sz]),
+        "p2_builder_add_lookup_from_index": (u64, [vp, u64, sz]),
+        "p2_builder_num_gates": (sz, [vp]),
+        "p2_builder_build": (C.c_int, [vp, C.POINTER(u8p), C.POINTER(sz)]), "p2_blob_free": (None, [u8p]),
+        "p2_aes_sbox_lut": (sz, [vp]), "p2_aes_byte_xor_lut": (sz, [vp]), "p2_aes_gf_2_8_mul_lut": (sz, [vp]),
+        "p2_gcm_u8_unit_right_shift_lut": (sz, [vp]), "p2_gcm_u8_bitref_lut": (sz, [vp]),
+        "p2_aes_add_virtual_byte_target": (u64, [vp, sz]), "p2_aes_add_virtual_byte_target_unsafe": (u64, [vp]),
+        "p2_aes_state_sub_bytes": (None, [vp, sz, u64p, u64p]),
+        "p2_aes_state_mix_columns": (None, [vp, sz, sz, u64p, u64p]),
+        "p2_aes_gf_2_8_mul": (u64, [vp, sz, u64, u64]), "p2_aes_gf_2_8_add": (u64, [vp, sz, u64, u64]),
+        "p2_aes_key_expansion": (None, [vp, C.c_int, C.c_int, sz, sz, u64p, u64p]),
+        "p2_aes_encrypt_block": (None, [vp, C.c_int, sz, sz, sz, u64p, u64p, u64p]),
+        "p2_gcm_gctr": (None, [vp, C.c_int, sz, sz, sz, u64p, u64p, u64p, sz, u64p]),
+        "p2_gcm_right_shift_one": (None, [vp, sz, u64p, u64p]), "p2_gcm_inc32": (None, [vp, u64p, u64p]),
+        "p2_gcm_gf_2_128_mul": (None, [vp, sz, sz, sz, u64p, u64p, u64p]),
+        "p2_gcm_ghash": (C.c_int, [vp, sz, sz, sz, u64p, u64p, sz, u64p]),
+        "p2_aes_gcm_build": (C.c_int, [vp, C.c_int, C.c_int, sz, C.c_int, u64p, u64p, u64p, u64p, u64p]),
+        "p2_native_gf_2_8_mul": (C.c_uint8, [C.c_uint8, C.c_uint8]),
+        "p2_native_aes_key_expansion": (None, [C.c_char_p, C.c_int, C.c_int, C.c_char_p]),
+        "p2_native_aes_encrypt_block": (None, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p]),
+        "p2_native_gf_2_128_mul": (None, [C.c_char_p, C.c_char_p, C.c_char_p]),
+        "p2_native_ghash": (None, [C.c_char_p, C.c_char_p, sz, C.c_char_p]),
+        "p2_native_gctr": (None, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, sz, C.c_char_p]),
+        "p2_native_aes_gcm_encrypt": (None, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, sz, C.c_char_p, C.c_char_p]),
+        "p2_blob_info": (C.c_int, [C.c_char_p, sz, C.POINTER(_Info)]),
+        "p2_verify": (C.c_int, [C.c_char_p, sz, u64p, sz, C.c_char_p, sz]),
+        "p2_circuit_load": (vp, [C.c_char_p, sz, C.c_int]), "p2_circuit_free": (None, [vp]),
+        "p2_circuit_verifier_data": (C.c_int, [vp, u64p, sz, C.POINTER(sz)]),
+        "p2_circuit_proof_bytes": (sz, [vp]),
+        "p2_prove_batch": (C.c_int, [vp, sz, C.POINTER(_Assignment), C.c_char_p, C.POINTER(C.c_int)]),
+        "p2_prove_batch_device": (C.c_int, [vp, sz, u64p, sz, vp, vp, vp, vp]),
+        "p2_circuit_synchronize": (C.c_int, [vp]),
+        "p2_circuit_set_timing": (C.c_int, [vp, C.c_int]),
+        "p2_circuit_get_timing": (sz, [vp, C.POINTER(_KernelTime), sz]),
+        "p2_gpu_device_count": (C.c_int, []),
+        "p2_gpu_poseidon": (C.c_int, [u64p, sz, C.c_int]),
+        "p2_gpu_lde": (C.c_int, [u64p, sz, C.c_int, C.c_int, u64p, C.c_int]),
+        "p2_gpu_intt": (C.c_int, [u64p, sz, C.c_int, u64p, C.c_int]),
+        "p2_gpu_merkle_cap": (C.c_int, [u64p, sz, sz, C.c_int, u64p, C.c_int]),
+        "p2_circuit_debug_read": (C.c_int, [vp, C.c_char_p, sz, u64p, sz, C.POINTER(sz)]),
+    }
+    missing = []
+    for name, (res, args) in sig.items():
+        try:
+            f = getattr(L, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        f.restype, f.argtypes = res, args
+    L._p2_missing = missing
+    L._p2_signatures = sig
+    _lib = L
+    return L
+
+
+def _err():
+    return lib().p2_last_error().decode()
+
+
+def _arr(vals):
+    return (u64 * len(vals))(*vals)
+
+
+class CircuitBuilder:
+    def __init__(self):
+        self._h = lib().p2_builder_new()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().p2_builder_free(self._h)
+            self._h = None
+
+    def add_virtual_target(self): return lib().p2_builder_add_virtual_target(self._h)
+    def add_virtual_target_arr(self, n): return [self.add_virtual_target() for _ in range(n)]
+    def constant(self, c): return lib().p2_builder_constant(self._h, c % P)
+    def zero(self): return lib().p2_builder_zero(self._h)
+    def one(self): return lib().p2_builder_one(self._h)
+    def arithmetic(self, c0, c1, m0, m1, addend): return lib().p2_builder_arithmetic(self._h, c0 % P, c1 % P, m0, m1, addend)
+    def mul_const_add(self, c, x, y): return lib().p2_builder_mul_const_add(self._h, c % P, x, y)
+    def add(self, x, y): return lib().p2_builder_add(self._h, x, y)
+    def sub(self, x, y): return lib().p2_builder_sub(self._h, x, y)
+    def mul(self, x, y): return lib().p2_builder_mul(self._h, x, y)
+    def select(self, b, x, y): return lib().p2_builder_select(self._h, b, x, y)
+    def is_equal(self, x, y): return lib().p2_builder_is_equal(self._h, x, y)
+    def connect(self, x, y): lib().p2_builder_connect(self._h, x, y)
+
+    def add_lookup_table_from_pairs(self, pairs):
+        flat = (C.c_uint16 * (2 * len(pairs)))(*[v for p in pairs for v in p])
+        return lib().p2_builder_add_lookup_table_from_pairs(self._h, flat, len(pairs))
+
+    def add_lookup_from_index(self, looking_in, lut_index):
+        t = lib().p2_builder_add_lookup_from_index(self._h, looking_in, lut_index)
+        if t == 0xFFFFFFFFFFFFFFFF:
+            raise P2Error(_err())
+        return t
+
+    def num_gates(self): return lib().p2_builder_num_gates(self._h)
+
+    # ---- CircuitBuilderAESState (aes-gcm/src/circuit_aes.rs:41-174) and the GCM helpers (circuit_gcm.rs)
+    def sbox_lut(self): return lib().p2_aes_sbox_lut(self._h)
+    def byte_xor_lut(self): return lib().p2_aes_byte_xor_lut(self._h)
+    def gf_2_8_mul_lut(self): return lib().p2_aes_gf_2_8_mul_lut(self._h)
+    def u8_unit_right_shift_lut(self): return lib().p2_gcm_u8_unit_right_shift_lut(self._h)
+    def u8_bitref_lut(self): return lib().p2_gcm_u8_bitref_lut(self._h)
+    def add_virtual_byte_target(self, u8_table_idx): return lib().p2_aes_add_virtual_byte_target(self._h, u8_table_idx)
+    def add_virtual_byte_target_unsafe(self): return lib().p2_aes_add_virtual_byte_target_unsafe(self._h)
+    def add_virtual_state_target_unsafe(self): return [self.add_virtual_byte_target_unsafe() for _ in range(16)]
+    def add_virtual_state_target(self, lut): return [self.add_virtual_byte_target(lut) for _ in range(16)]
+
+    def state_sub_bytes(self, sbox_lut, s):
+        out = (u64 * 16)()
+        lib().p2_aes_state_sub_bytes(self._h, sbox_lut, _arr(s), out)
+        return list(out)
+
+    def state_mix_columns(self, xor_lut, mul_lut, s):
+        out = (u64 * 16)()
+        lib().p2_aes_state_mix_columns(self._h, xor_lut, mul_lut, _arr(s), out)
+        return list(out)
+
+    def gf_2_8_mul(self, mul_lut, x, y): return lib().p2_aes_gf_2_8_mul(self._h, mul_lut, x, y)
+    def gf_2_8_add(self, xor_lut, x, y): return lib().p2_aes_gf_2_8_add(self._h, xor_lut, x, y)
+
+    def key_expansion(self, nk, nr, xor_lut, sbox_lut, key):
+        out = (u64 * (16 * (nr + 1)))()
+        lib().p2_aes_key_expansion(self._h, nk, nr, xor_lut, sbox_lut, _arr(key), out)
+        return list(out)
+
+    def encrypt_block(self, nr, xor_lut, mul_lut, sbox_lut, state, expanded_key):
+        out = (u64 * 16)()
+        lib().p2_aes_encrypt_block(self._h, nr, xor_lut, mul_lut, sbox_lut, _arr(state), _arr(expanded_key), out)
+        return list(out)
+
+    def gctr(self, nr, xor_lut, mul_lut, sbox_lut, expanded_key, icb, x):
+        out = (u64 * len(x))()
+        lib().p2_gcm_gctr(self._h, nr, xor_lut, mul_lut, sbox_lut, _arr(expanded_key), _arr(icb), _arr(x), len(x), out)
+        return list(out)
+
+    def right_shift_one(self, shift_lut, v):
+        out = (u64 * 16)()
+        lib().p2_gcm_right_shift_one(self._h, shift_lut, _arr(v), out)
+        return list(out)
+
+    def inc32(self, block):
+        out = (u64 * 16)()
+        lib().p2_gcm_inc32(self._h, _arr(block), out)
+        return list(out)
+
+    def gf_2_128_mul(self, xor_lut, shift_lut, bitref_lut, x, y):
+        out = (u64 * 16)()
+        lib().p2_gcm_gf_2_128_mul(self._h, xor_lut, shift_lut, bitref_lut, _arr(x), _arr(y), out)
+        return list(out)
+
+    def ghash(self, xor_lut, shift_lut, bitref_lut, h, x):
+        out = (u64 * 16)()
+        if lib().p2_gcm_ghash(self._h, xor_lut, shift_lut, bitref_lut, _arr(h), _arr(x), len(x), out):
+            raise P2Error(_err())
+        return list(out)
+
+    def build(self):
+        blob, n = u8p(), sz()
+        if lib().p2_builder_build(self._h, C.byref(blob), C.byref(n)):
+            raise P2Error(_err())
+        data = C.string_at(blob, n.value)
+        lib().p2_blob_free(blob)
+        return CircuitData(data)
+
+
+class PartialWitness:
+    """plonky2 iop::witness::PartialWitness: a target -> value map; set_target errors on a conflicting re-set."""
+
+    def __init__(self):
+        self.map = {}
+
+    def set_target(self, target, value):
+        value = int(value)
+        if not 0 <= value < P:
+            raise P2Error("value is not a canonical field element")
+        old = self.map.get(target)
+        if old is not None and old != value:
+            raise P2Error("target was set twice with different values")
+        self.map[target] = value
+
+    def set_target_arr(self, targets, values):
+        for t, v in zip(targets, values):
+            self.set_target(t, v)
+
+    # PartialWitnessByteArray / PartialWitnessAESState (circuit_aes.rs:277-297)
+    def set_byte_target(self, target, value): self.set_target(target, value & 0xFF if isinstance(value, int) else int(value))
+    def set_state_target(self, targets, state16):
+        for t, v in zip(targets, state16):
+            self.set_byte_target(t, v)
+
+
+class CircuitData:
+    """builder.build::<PoseidonGoldilocksConfig>() result.  prove() runs on the GPU (no CPU fallback)."""
+
+    def __init__(self, blob, device=0):
+        self.blob = blob
+        self.device = device
+        self._gpu = None
+        info = _Info()
+        if lib().p2_blob_info(blob, len(blob), C.byref(info)):
+            raise P2Error(_err())
+        self.info = {n: getattr(info, n) for n, _ in _Info._fields_}
+
+    def __del__(self):
+        if getattr(self, "_gpu", None):
+            lib().p2_circuit_free(self._gpu)
+            self._gpu = None
+
+    def gpu(self):
+        if self._gpu is None:
+            h = lib().p2_circuit_load(self.blob, len(self.blob), self.device)
+            if not h:
+                raise P2Error("p2_circuit_load failed: " + _err())
+            self._gpu = h
+        return self._gpu
+
+    @property
+    def proof_bytes(self): return self.info["proof_bytes"]
+
+    def verifier_data(self):
+        out = (u64 * 80)()
+        n = sz()
+        if lib().p2_circuit_verifier_data(self.gpu(), out, 80, C.byref(n)):
+            raise P2Error(_err())
+        return list(out[: n.value])
+
+    def prove_batch(self, pws):
+        """Returns (proofs: list[bytes|None], status: list[int])."""
+        B = len(pws)
+        asg = (_Assignment * B)()
+        keep = []
+        for i, pw in enumerate(pws):
+            ts, vs = _arr(list(pw.map.keys())), _arr(list(pw.map.values()))
+            keep.append((ts, vs))
+            asg[i].targets, asg[i].values, asg[i].count = C.cast(ts, u64p), C.cast(vs, u64p), len(pw.map)
+        buf = C.create_string_buffer(B * self.proof_bytes)
+        status = (C.c_int * B)()
+        if lib().p2_prove_batch(self.gpu(), B, asg, buf, status):
+            raise P2Error("p2_prove_batch failed: " + _err())
+        pb = self.proof_bytes
+        return [buf.raw[i * pb:(i + 1) * pb] if status[i] == 0 else None for i in range(B)], list(status)
+
+    def prove(self, pw):
+        proofs, status = self.prove_batch([pw])
+        if status[0]:
+            raise ProveError(status[0])
+        return proofs[0]
+
+    def verify(self, proof, verifier_data=None):
+        vd = verifier_data if verifier_data is not None else self.verifier_data()
+        if lib().p2_verify(self.blob, len(self.blob), _arr(vd), len(vd), proof, len(proof)):
+            raise P2Error("verify failed: " + _err())
+
+    def debug_read(self, name, index=0, cap=1 << 26):
+        out = (u64 * cap)()
+        n = sz()
+        if lib().p2_circuit_debug_read(self.gpu(), name.encode(), index, out, cap, C.byref(n)):
+            raise P2Error(_err())
+        return list(out[: n.value])
+
+
+class AesGcmTarget:
+    """AesGcmTarget<NK, 4, NR, L, TAG> (aes-gcm/src/circuit_gcm.rs:24-209)."""
+
+    @staticmethod
+    def build(builder, nk=4, nr=10, L=16, tag=False):
+        t = AesGcmTarget()
+        t.nk, t.nr, t.L, t.TAG = nk, nr, L, tag
+        key, nonce, pt, ct, tg = (u64 * (4 * nk))(), (u64 * 12)(), (u64 * max(L, 1))(), (u64 * max(L, 1))(), (u64 * 16)()
+        if lib().p2_aes_gcm_build(builder._h, nk, nr, L, int(tag), key, nonce, pt, ct, tg):
+            raise P2Error(_err())
+        t.key, t.nonce, t.pt, t.ct, t.tag = list(key), list(nonce), list(pt)[:L], list(ct)[:L], list(tg)
+        return t
+
+    def set_targets(self, pw, key, nonce, pt, ct, tag):
+        # effective contract of circuit_gcm.rs:183-193: len(pt) == len(ct) == L (copy_from_slice panics otherwise)
+        assert len(pt) == self.L and len(ct) == self.L and len(key) == 4 * self.nk and len(nonce) == 12
+        for t, v in zip(self.key, key): pw.set_byte_target(t, v)
+        for t, v in zip(self.nonce, nonce): pw.set_byte_target(t, v)
+        for t, v in zip(self.pt, pt): pw.set_byte_target(t, v)
+        for t, v in zip(self.ct, ct): pw.set_byte_target(t, v)
+        if self.TAG:
+            assert len(tag) == 16
+            for t, v in zip(self.tag, tag): pw.set_byte_target(t, v)
+        else:
+            for t in self.tag: pw.set_byte_target(t, 0)
+
+
+class native:
+    """aes-gcm/src/native_aes.rs / native_gcm.rs through the C ABI."""
+
+    @staticmethod
+    def gf_2_8_mul(a, b): return lib().p2_native_gf_2_8_mul(a, b)
+
+    @staticmethod
+    def key_expansion(key):
+        nk = len(key) // 4
+        out = C.create_string_buffer(16 * (nk + 7))
+        lib().p2_native_aes_key_expansion(bytes(key), nk, nk + 6, out)
+        return out.raw
+
+    @staticmethod
+    def encrypt_block(key, block):
+        nk = len(key) // 4
+        out = C.create_string_buffer(16)
+        lib().p2_native_aes_encrypt_block(bytes(key), nk, nk + 6, bytes(block), out)
+        return out.raw
+
+    @staticmethod
+    def gf_2_128_mul(x, y):
+        out = C.create_string_buffer(16)
+        lib().p2_native_gf_2_128_mul(bytes(x), bytes(y), out)
+        return out.raw
+
+    @staticmethod
+    def ghash(h, x):
+        out = C.create_string_buffer(16)
+        lib().p2_native_ghash(bytes(h), bytes(x), len(x), out)
+        return out.raw
+
+    @staticmethod
+    def gctr(key, icb, x):
+        nk = len(key) // 4
+        out = C.create_string_buffer(max(len(x), 1))
+        lib().p2_native_gctr(bytes(key), nk, nk + 6, bytes(icb), bytes(x), len(x), out)
+        return out.raw[: len(x)]
+
+    @staticmethod
+    def gcm_encrypt(key, nonce, pt):
+        nk = len(key) // 4
+        ct, tag = C.create_string_buffer(max(len(pt), 1)), C.create_string_buffer(16)
+        lib().p2_native_aes_gcm_encrypt(bytes(key), nk, nk + 6, bytes(nonce), bytes(pt), len(pt), ct, tag)
+        return ct.raw[: len(pt)], tag.raw

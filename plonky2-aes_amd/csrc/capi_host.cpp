@@ -1,0 +1,220 @@
+// Host half of the C ABI declared in include/p2aes.h: CircuitBuilder mirror, AES/GCM gadgets, native cipher,
+// blob info and the verifier.  No device code here; the GPU prover lives in prover_gpu.hip.
+#include <stdlib.h>
+
+#include "../../include/p2aes.h"
+#include "aes_gadgets.h"
+#include "capi_common.h"
+#include "verifier.h"
+
+using namespace p2;
+
+namespace p2 {
+thread_local std::string g_last_error;
+}
+
+struct p2_builder {
+    CircuitBuilder b;
+};
+
+extern "C" {
+
+const char* p2_last_error(void) { return p2::g_last_error.c_str(); }
+
+p2_builder* p2_builder_new(void) { return new p2_builder(); }
+void p2_builder_free(p2_builder* b) { delete b; }
+p2_target p2_builder_add_virtual_target(p2_builder* b) { return b->b.add_virtual_target(); }
+p2_target p2_builder_constant(p2_builder* b, uint64_t c) { return b->b.constant(c); }
+p2_target p2_builder_zero(p2_builder* b) { return b->b.zero(); }
+p2_target p2_builder_one(p2_builder* b) { return b->b.one(); }
+p2_target p2_builder_arithmetic(p2_builder* b, uint64_t c0, uint64_t c1, p2_target m0, p2_target m1, p2_target a) {
+    return b->b.arithmetic(c0 % gl::P, c1 % gl::P, m0, m1, a);
+}
+p2_target p2_builder_mul_const_add(p2_builder* b, uint64_t c, p2_target x, p2_target y) { return b->b.mul_const_add(c % gl::P, x, y); }
+p2_target p2_builder_add(p2_builder* b, p2_target x, p2_target y) { return b->b.add(x, y); }
+p2_target p2_builder_sub(p2_builder* b, p2_target x, p2_target y) { return b->b.sub(x, y); }
+p2_target p2_builder_mul(p2_builder* b, p2_target x, p2_target y) { return b->b.mul(x, y); }
+p2_target p2_builder_select(p2_builder* b, p2_target c, p2_target x, p2_target y) { return b->b.select(BoolTarget{c}, x, y); }
+p2_target p2_builder_is_equal(p2_builder* b, p2_target x, p2_target y) { return b->b.is_equal(x, y).target; }
+void p2_builder_connect(p2_builder* b, p2_target x, p2_target y) { b->b.connect(x, y); }
+size_t p2_builder_add_lookup_table_from_pairs(p2_builder* b, const uint16_t* pairs, size_t n) {
+    std::vector<std::pair<u16, u16>> t(n);
+    for (size_t i = 0; i < n; i++) t[i] = {pairs[2 * i], pairs[2 * i + 1]};
+    return b->b.add_lookup_table_from_pairs(t);
+}
+p2_target p2_builder_add_lookup_from_index(p2_builder* b, p2_target in, size_t lut) {
+    try {
+        return b->b.add_lookup_from_index(in, lut);
+    } catch (std::exception& e) {
+        set_error(e.what());
+        return UINT64_MAX;
+    }
+}
+size_t p2_builder_num_gates(const p2_builder* b) { return b->b.num_gates(); }
+int p2_builder_build(p2_builder* b, uint8_t** blob, size_t* len) {
+    try {
+        Circuit c = b->b.build();
+        std::vector<uint8_t> v = serialize(c);
+        uint8_t* out = (uint8_t*)malloc(v.size());
+        if (!out) return set_error("out of memory"), P2_ERR_INVALID;
+        memcpy(out, v.data(), v.size());
+        *blob = out;
+        *len = v.size();
+        return P2_OK;
+    } catch (std::exception& e) {
+        return set_error(e.what()), P2_ERR_INVALID;
+    }
+}
+void p2_blob_free(uint8_t* blob) { free(blob); }
+
+// ---- gadgets
+static aes::StateTarget state_in(const p2_target* s) {
+    aes::StateTarget st;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) st[i][j] = s[4 * i + j];
+    return st;
+}
+static void state_out(const aes::StateTarget& st, p2_target* o) {
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) o[4 * i + j] = st[i][j];
+}
+static std::vector<aes::WordTarget> words_in(const p2_target* w, size_t n) {
+    std::vector<aes::WordTarget> v(n);
+    for (size_t i = 0; i < n; i++)
+        for (int j = 0; j < 4; j++) v[i][j] = w[4 * i + j];
+    return v;
+}
+static aes::BlockTarget block_in(const p2_target* b) {
+    aes::BlockTarget r;
+    for (int i = 0; i < 16; i++) r[i] = b[i];
+    return r;
+}
+size_t p2_aes_sbox_lut(p2_builder* b) { return aes::sbox_lut(b->b); }
+size_t p2_aes_byte_xor_lut(p2_builder* b) { return aes::byte_xor_lut(b->b); }
+size_t p2_aes_gf_2_8_mul_lut(p2_builder* b) { return aes::gf_2_8_mul_lut(b->b); }
+size_t p2_gcm_u8_unit_right_shift_lut(p2_builder* b) { return aes::u8_unit_right_shift_lut(b->b); }
+size_t p2_gcm_u8_bitref_lut(p2_builder* b) { return aes::u8_bitref_lut(b->b); }
+p2_target p2_aes_add_virtual_byte_target(p2_builder* b, size_t t) {
+    try {
+        return aes::add_virtual_byte_target(b->b, t);
+    } catch (std::exception& e) {
+        set_error(e.what());
+        return UINT64_MAX;
+    }
+}
+p2_target p2_aes_add_virtual_byte_target_unsafe(p2_builder* b) { return aes::add_virtual_byte_target_unsafe(b->b); }
+void p2_aes_state_sub_bytes(p2_builder* b, size_t sbox, const p2_target* s, p2_target* out) { state_out(aes::state_sub_bytes(b->b, sbox, state_in(s)), out); }
+void p2_aes_state_mix_columns(p2_builder* b, size_t xl, size_t ml, const p2_target* s, p2_target* out) {
+    aes::StateTarget mix = aes::state_mix_matrix(b->b);
+    state_out(aes::state_mix_columns(b->b, xl, ml, mix, state_in(s)), out);
+}
+p2_target p2_aes_gf_2_8_mul(p2_builder* b, size_t ml, p2_target x, p2_target y) { return aes::gf_2_8_mul_t(b->b, ml, x, y); }
+p2_target p2_aes_gf_2_8_add(p2_builder* b, size_t xl, p2_target x, p2_target y) { return aes::gf_2_8_add(b->b, xl, x, y); }
+void p2_aes_key_expansion(p2_builder* b, int nk, int nr, size_t xl, size_t sl, const p2_target* key, p2_target* out) {
+    std::vector<aes::ByteTarget> k(key, key + 4 * nk);
+    auto w = aes::key_expansion_t(b->b, nk, nr, xl, sl, k);
+    for (size_t i = 0; i < w.size(); i++)
+        for (int j = 0; j < 4; j++) out[4 * i + j] = w[i][j];
+}
+void p2_aes_encrypt_block(p2_builder* b, int nr, size_t xl, size_t ml, size_t sl, const p2_target* state, const p2_target* ek, p2_target* out) {
+    aes::StateTarget mix = aes::state_mix_matrix(b->b);
+    state_out(aes::encrypt_block_t(b->b, nr, xl, ml, sl, mix, state_in(state), words_in(ek, 4 * (nr + 1))), out);
+}
+void p2_gcm_gctr(p2_builder* b, int nr, size_t xl, size_t ml, size_t sl, const p2_target* ek, const p2_target* icb, const p2_target* x, size_t len, p2_target* y) {
+    aes::StateTarget mix = aes::state_mix_matrix(b->b);
+    std::vector<aes::ByteTarget> xv(x, x + len);
+    auto r = aes::gctr_target(b->b, nr, xl, ml, sl, mix, words_in(ek, 4 * (nr + 1)), block_in(icb), xv);
+    for (size_t i = 0; i < len; i++) y[i] = r[i];
+}
+void p2_gcm_right_shift_one(p2_builder* b, size_t shl, const p2_target* v, p2_target* out) {
+    auto r = aes::right_shift_one_target(b->b, shl, block_in(v));
+    for (int i = 0; i < 16; i++) out[i] = r[i];
+}
+void p2_gcm_inc32(p2_builder* b, const p2_target* blk, p2_target* out) {
+    auto r = aes::inc32_target(b->b, block_in(blk));
+    for (int i = 0; i < 16; i++) out[i] = r[i];
+}
+void p2_gcm_gf_2_128_mul(p2_builder* b, size_t xl, size_t shl, size_t brl, const p2_target* x, const p2_target* y, p2_target* out) {
+    auto r = aes::gf_2_128_mul_target(b->b, xl, shl, brl, block_in(x), block_in(y));
+    for (int i = 0; i < 16; i++) out[i] = r[i];
+}
+int p2_gcm_ghash(p2_builder* b, size_t xl, size_t shl, size_t brl, const p2_target* h, const p2_target* x, size_t len, p2_target* out) {
+    try {
+        std::vector<aes::ByteTarget> xv(x, x + len);
+        auto r = aes::ghash_target(b->b, xl, shl, brl, block_in(h), xv);
+        for (int i = 0; i < 16; i++) out[i] = r[i];
+        return P2_OK;
+    } catch (std::exception& e) {
+        return set_error(e.what()), P2_ERR_INVALID;
+    }
+}
+int p2_aes_gcm_build(p2_builder* b, int nk, int nr, size_t L, int with_tag, p2_target* key, p2_target* nonce, p2_target* pt, p2_target* ct, p2_target* tag) {
+    if (!((nk == 4 && nr == 10) || (nk == 6 && nr == 12) || (nk == 8 && nr == 14))) return set_error("unsupported (NK, NR)"), P2_ERR_INVALID;
+    try {
+        auto t = aes::AesGcmTarget::build(b->b, nk, nr, L, with_tag != 0);
+        std::copy(t.key.begin(), t.key.end(), key);
+        std::copy(t.nonce.begin(), t.nonce.end(), nonce);
+        std::copy(t.pt.begin(), t.pt.end(), pt);
+        std::copy(t.ct.begin(), t.ct.end(), ct);
+        std::copy(t.tag.begin(), t.tag.end(), tag);
+        return P2_OK;
+    } catch (std::exception& e) {
+        return set_error(e.what()), P2_ERR_INVALID;
+    }
+}
+
+// ---- native cipher
+uint8_t p2_native_gf_2_8_mul(uint8_t a, uint8_t b) { return aes::gf_2_8_mul(a, b); }
+void p2_native_aes_key_expansion(const uint8_t* key, int nk, int nr, uint8_t* out) {
+    auto w = aes::key_expansion(nk, nr, key);
+    for (size_t i = 0; i < w.size(); i++) memcpy(out + 4 * i, w[i].data(), 4);
+}
+void p2_native_aes_encrypt_block(const uint8_t* key, int nk, int nr, const uint8_t* in, uint8_t* out) {
+    auto w = aes::key_expansion(nk, nr, key);
+    auto s = aes::flatten_state(aes::encrypt_block(nr, in, w));
+    memcpy(out, s.data(), 16);
+}
+void p2_native_gf_2_128_mul(const uint8_t* x, const uint8_t* y, uint8_t* out) {
+    auto r = aes::gf_2_128_mul(x, y);
+    memcpy(out, r.data(), 16);
+}
+void p2_native_ghash(const uint8_t* h, const uint8_t* x, size_t len, uint8_t* out) {
+    auto r = aes::ghash(h, x, len);
+    memcpy(out, r.data(), 16);
+}
+void p2_native_gctr(const uint8_t* key, int nk, int nr, const uint8_t* icb, const uint8_t* x, size_t len, uint8_t* y) {
+    auto w = aes::key_expansion(nk, nr, key);
+    auto r = aes::gctr(nr, w, icb, x, len);
+    if (len) memcpy(y, r.data(), len);
+}
+void p2_native_aes_gcm_encrypt(const uint8_t* key, int nk, int nr, const uint8_t* nonce, const uint8_t* pt, size_t len, uint8_t* ct, uint8_t* tag) {
+    aes::gcm_encrypt(nk, nr, key, nonce, pt, len, ct, tag);
+}
+
+// ---- info / verify
+int p2_blob_info(const uint8_t* blob, size_t len, p2_circuit_info* out) {
+    try {
+        Circuit c = deserialize(blob, len);
+        fill_info(c, out);
+        return P2_OK;
+    } catch (std::exception& e) {
+        return set_error(e.what()), P2_ERR_INVALID;
+    }
+}
+int p2_verify(const uint8_t* blob, size_t blob_len, const uint64_t* vd, size_t vd_len, const uint8_t* proof, size_t proof_len) {
+    try {
+        Circuit c = deserialize(blob, blob_len);
+        size_t cap_n = (size_t)1 << c.cfg.cap_height;
+        if (vd_len != 4 * cap_n + 4) return set_error("verifier_data must be cap || circuit_digest"), P2_ERR_INVALID;
+        VerifierData v;
+        v.constants_sigmas_cap.resize(cap_n);
+        for (size_t i = 0; i < cap_n; i++) memcpy(v.constants_sigmas_cap[i].e, vd + 4 * i, 32);
+        memcpy(v.circuit_digest.e, vd + 4 * cap_n, 32);
+        std::string err = verify_proof(c, v, proof, proof_len);
+        if (!err.empty()) return set_error(err), P2_ERR_VERIFY;
+        return P2_OK;
+    } catch (std::exception& e) {
+        return set_error(e.what()), P2_ERR_INVALID;
+    }
+}
+}

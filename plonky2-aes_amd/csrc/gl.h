@@ -1,0 +1,233 @@
+// Goldilocks field (p = 2^64 - 2^32 + 1), its quadratic extension GF(p^2) = F[x]/(x^2 - 7) and the
+// Poseidon-12 permutation, written once for host (g++) and device (hipcc, gfx950).
+//
+// What this replaces: plonky2::field::goldilocks_field::GoldilocksField, field::extension::quadratic and
+// hash::poseidon (third-party crate `plonky2`, git rev 109d517d..., /root/reference/Cargo.toml:12 -- source
+// not vendored; algorithm restated from its published definition).
+//
+// All values are kept CANONICAL (< p) after every operation so that buffers can be compared bit-for-bit
+// with the CPU oracle.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GL_HD __host__ __device__ __forceinline__
+#define GL_D __device__ __forceinline__
+#else
+#define GL_HD inline
+#define GL_D inline
+#endif
+
+namespace gl {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+static const u64 P = 0xFFFFFFFF00000001ULL;
+static const u64 EPS = 0xFFFFFFFFULL;  // 2^64 mod p
+// plonky2 GoldilocksField::MULTIPLICATIVE_GROUP_GENERATOR / POWER_OF_TWO_GENERATOR (second pair)
+static const u64 MULT_GEN = 14293326489335486720ULL;
+static const u64 POW2_GEN = 7277203076849721926ULL;  // order 2^32
+static const u64 W_EXT = 7;                          // x^2 = 7
+
+GL_HD u64 add(u64 a, u64 b) {
+    u64 s = a + b;
+    // a,b < p so a+b < 2p < 2^65; overflow or s>=p => subtract p once.
+    if (s < a || s >= P) s -= P;
+    return s;
+}
+GL_HD u64 sub(u64 a, u64 b) { return a >= b ? a - b : a + (P - b); }
+GL_HD u64 neg(u64 a) { return a ? P - a : 0; }
+GL_HD u64 dbl(u64 a) { return add(a, a); }
+
+GL_HD void mul64(u64 a, u64 b, u64& hi, u64& lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    lo = a * b;
+    hi = __umul64hi(a, b);
+#else
+    unsigned __int128 m = (unsigned __int128)a * b;
+    lo = (u64)m;
+    hi = (u64)(m >> 64);
+#endif
+}
+
+// Reduce hi*2^64 + lo mod p to canonical form, using 2^64 = 2^32 - 1 and 2^96 = -1 (mod p).
+GL_HD u64 reduce128(u64 hi, u64 lo) {
+    u64 hi_hi = hi >> 32, hi_lo = hi & EPS;
+    u64 t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= EPS;  // borrow: add p == subtract 2^32-1 (mod 2^64)
+    u64 t1 = hi_lo * EPS;       // < 2^64
+    u64 r = t0 + t1;
+    if (r < t1) r += EPS;  // carry: 2^64 = EPS mod p
+    if (r >= P) r -= P;
+    return r;
+}
+GL_HD u64 mul(u64 a, u64 b) {
+    u64 hi, lo;
+    mul64(a, b, hi, lo);
+    return reduce128(hi, lo);
+}
+GL_HD u64 sqr(u64 a) { return mul(a, a); }
+// a*b + c
+GL_HD u64 mul_add(u64 a, u64 b, u64 c) { return add(mul(a, b), c); }
+
+GL_HD u64 pow(u64 b, u64 e) {
+    u64 r = 1;
+    while (e) {
+        if (e & 1) r = mul(r, b);
+        b = sqr(b);
+        e >>= 1;
+    }
+    return r;
+}
+GL_HD u64 exp_pow2(u64 b, int k) {
+    for (int i = 0; i < k; i++) b = sqr(b);
+    return b;
+}
+// Fermat inverse (0 -> 0).
+GL_HD u64 inv(u64 a) { return pow(a, P - 2); }
+
+// primitive 2^k-th root of unity, as plonky2 `primitive_root_of_unity(k)`
+GL_HD u64 root_of_unity(int k) { return exp_pow2(POW2_GEN, 32 - k); }
+
+GL_HD u32 bitrev(u32 x, int bits) {
+    u32 r = 0;
+    for (int i = 0; i < bits; i++) {
+        r = (r << 1) | (x & 1);
+        x >>= 1;
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------- GF(p^2)
+struct E2 {
+    u64 a, b;  // a + b*x
+};
+GL_HD E2 e2(u64 a, u64 b = 0) {
+    E2 r;
+    r.a = a;
+    r.b = b;
+    return r;
+}
+GL_HD E2 add(E2 x, E2 y) { return e2(add(x.a, y.a), add(x.b, y.b)); }
+GL_HD E2 sub(E2 x, E2 y) { return e2(sub(x.a, y.a), sub(x.b, y.b)); }
+GL_HD E2 mul(E2 x, E2 y) {
+    // (a0 + a1 x)(b0 + b1 x) = a0b0 + 7 a1b1 + (a0b1 + a1b0) x
+    u64 a0b0 = mul(x.a, y.a), a1b1 = mul(x.b, y.b);
+    u64 c0 = add(a0b0, mul(a1b1, W_EXT));
+    u64 c1 = add(mul(x.a, y.b), mul(x.b, y.a));
+    return e2(c0, c1);
+}
+GL_HD E2 mul(E2 x, u64 s) { return e2(mul(x.a, s), mul(x.b, s)); }
+GL_HD E2 sqr(E2 x) { return mul(x, x); }
+GL_HD bool eq(E2 x, E2 y) { return x.a == y.a && x.b == y.b; }
+GL_HD E2 inv(E2 x) {
+    // 1/(a + b x) = (a - b x) / (a^2 - 7 b^2)
+    u64 d = sub(sqr(x.a), mul(W_EXT, sqr(x.b)));
+    u64 di = inv(d);
+    return e2(mul(x.a, di), mul(neg(x.b), di));
+}
+GL_HD E2 pow(E2 b, u64 e) {
+    E2 r = e2(1, 0);
+    while (e) {
+        if (e & 1) r = mul(r, b);
+        b = sqr(b);
+        e >>= 1;
+    }
+    return r;
+}
+GL_HD E2 exp_pow2(E2 b, int k) {
+    for (int i = 0; i < k; i++) b = sqr(b);
+    return b;
+}
+
+// ---------------------------------------------------------------- Poseidon-12
+static const u64 H_POSEIDON_RC[360] = {
+#include "poseidon_rc.inc"
+};
+#if defined(__HIPCC__)
+__device__ __constant__ static const u64 D_POSEIDON_RC[360] = {
+#include "poseidon_rc.inc"
+};
+#endif
+GL_HD u64 poseidon_rc(int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return D_POSEIDON_RC[i];
+#else
+    return H_POSEIDON_RC[i];
+#endif
+}
+
+static const int SPONGE_WIDTH = 12;
+static const int SPONGE_RATE = 8;
+
+GL_HD u64 sbox7(u64 x) {
+    u64 x2 = sqr(x), x4 = sqr(x2), x3 = mul(x2, x);
+    return mul(x4, x3);
+}
+
+// MDS: out[r] = sum_i circ[i] * s[(i+r)%12] + diag[r]*s[r], circ = [17,15,41,16,2,28,13,13,39,18,34,20], diag=[8,0..]
+// Evaluated on 32-bit halves so every accumulator fits in 64 bits (coefficients < 2^6, 12 terms).
+GL_HD void mds_layer(u64* s) {
+    const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    u64 lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        lo[i] = s[i] & EPS;
+        hi[i] = s[i] >> 32;
+    }
+    u64 out[12];
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+        u64 al = 0, ah = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            int j = (i + r) % 12;
+            al += lo[j] * C[i];
+            ah += hi[j] * C[i];
+        }
+        if (r == 0) {
+            al += lo[0] * 8;
+            ah += hi[0] * 8;
+        }
+        // value = al + ah*2^32, al,ah < 2^42.  hi word = ah>>32, lo word = al + (ah<<32) with carry.
+        u64 l = al + (ah << 32);
+        u64 h = (ah >> 32) + (l < al ? 1 : 0);
+        out[r] = reduce128(h, l);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = out[i];
+}
+
+// Full permutation, "naive" schedule: 4 full + 22 partial + 4 full rounds; each round = add constants,
+// S-box x^7 (all lanes / lane 0), MDS.  plonky2's optimised partial rounds compute the same function.
+GL_HD void poseidon(u64* s) {
+    int rc = 0;
+    for (int r = 0; r < 30; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = add(s[i], poseidon_rc(rc + i));
+        rc += 12;
+        if (r < 4 || r >= 26) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) s[i] = sbox7(s[i]);
+        } else {
+            s[0] = sbox7(s[0]);
+        }
+        mds_layer(s);
+    }
+}
+
+// two_to_one(l, r) = permute(l || r || 0^4)[0..4]   (plonky2 hash::hashing::compress)
+GL_HD void two_to_one(const u64* l, const u64* r, u64* out) {
+    u64 s[12];
+    for (int i = 0; i < 4; i++) {
+        s[i] = l[i];
+        s[4 + i] = r[i];
+        s[8 + i] = 0;
+    }
+    poseidon(s);
+    for (int i = 0; i < 4; i++) out[i] = s[i];
+}
+
+}  // namespace gl
