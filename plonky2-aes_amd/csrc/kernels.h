@@ -1,0 +1,647 @@
+// HIP kernels of the proving pipeline (gfx950 / MI355X).  64-bit modular integer work: no MFMA anywhere;
+// the levers are coalesced column-major access, LDS-resident butterflies and enough waves to cover latency.
+//
+// Data layout (all u64, canonical field elements):
+//   polynomial batches are COLUMN-MAJOR: values/coeffs [col][n], LDE [col][8n] with the LDE index already
+//   bit-reversed (position p holds the value at g*w^rev(p)), i.e. exactly plonky2's Merkle leaf order, so a
+//   leaf is the p-th element of every column and a wave reading 64 consecutive leaves of one column issues one
+//   512-byte coalesced request.  A batch of proofs adds an outer [proof] dimension (blockIdx.y).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "circuit.h"
+#include "gl.h"
+
+namespace p2k {
+using gl::E2;
+using gl::u32;
+using gl::u64;
+
+static const u64 UNSET = ~0ull;
+
+// ------------------------------------------------------------------------------------------- Poseidon
+// 12 lanes of state live in registers of ONE thread; one thread = one sponge.  (Leaf hashing has ~10^5..10^6
+// independent sponges per tree, so thread-per-sponge already fills the chip with coalesced column reads.)
+__device__ __forceinline__ void sponge_absorb_permute(u64* st) { gl::poseidon(st); }
+
+// Leaf digests of a column-major batch: digest[leaf] = hash_or_noop(row leaf of `cols` columns).
+// Columns >= active_cols are known-zero (never materialised).
+__global__ __launch_bounds__(256) void k_hash_leaves(const u64* __restrict__ data, int cols, int active_cols, size_t col_stride,
+                                                      size_t batch_stride, size_t num_leaves, u64* __restrict__ digests,
+                                                      size_t dig_batch_stride) {
+    size_t leaf = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= num_leaves) return;
+    const u64* d = data + (size_t)blockIdx.y * batch_stride + leaf;
+    u64* out = digests + (size_t)blockIdx.y * dig_batch_stride + leaf * 4;
+    u64 st[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = 0;
+    if (cols <= 4) {
+        for (int c = 0; c < 4; c++) out[c] = (c < cols && c < active_cols) ? d[(size_t)c * col_stride] : 0;
+        return;
+    }
+    for (int c0 = 0; c0 < cols; c0 += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            int c = c0 + k;
+            if (c < cols) st[k] = c < active_cols ? d[(size_t)c * col_stride] : 0;
+        }
+        gl::poseidon(st);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = st[i];
+}
+
+// FRI commit-phase leaves: leaf t = 16 consecutive extension values (bit-reversed order), flattened (c0,c1).
+// values: two component columns [2][len].
+__global__ __launch_bounds__(256) void k_hash_fri_leaves(const u64* __restrict__ vals, size_t len, size_t batch_stride, int arity,
+                                                          u64* __restrict__ digests, size_t dig_batch_stride) {
+    size_t leaf = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t num_leaves = len / arity;
+    if (leaf >= num_leaves) return;
+    const u64* v = vals + (size_t)blockIdx.y * batch_stride;
+    u64 st[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = 0;
+    int width = 2 * arity;
+    for (int e0 = 0; e0 < width; e0 += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            int e = e0 + k;
+            if (e < width) st[k] = v[(size_t)(e & 1) * len + leaf * arity + (e >> 1)];
+        }
+        gl::poseidon(st);
+    }
+    u64* out = digests + (size_t)blockIdx.y * dig_batch_stride + leaf * 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = st[i];
+}
+
+// One Merkle level: parent[i] = two_to_one(child[2i], child[2i+1]).
+__global__ __launch_bounds__(256) void k_merkle_level(const u64* __restrict__ child, u64* __restrict__ parent, size_t num_parents,
+                                                       size_t batch_stride) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_parents) return;
+    const u64* c = child + (size_t)blockIdx.y * batch_stride + 8 * i;
+    u64 st[12];
+#pragma unroll
+    for (int k = 0; k < 8; k++) st[k] = c[k];
+#pragma unroll
+    for (int k = 8; k < 12; k++) st[k] = 0;
+    gl::poseidon(st);
+    u64* o = parent + (size_t)blockIdx.y * batch_stride + 4 * i;
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = st[k];
+}
+
+// standalone permutation (parity test entry point)
+__global__ void k_poseidon_states(u64* states, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 st[12];
+    for (int k = 0; k < 12; k++) st[k] = states[12 * i + k];
+    gl::poseidon(st);
+    for (int k = 0; k < 12; k++) states[12 * i + k] = st[k];
+}
+
+// ------------------------------------------------------------------------------------------- NTT
+// One workgroup transforms one column (n = 2^logn <= 2^14 points, 8 B each => up to 128 KiB of the CU's
+// 160 KiB LDS), decimation in frequency: natural order in, bit-reversed order out, log n LDS stages.
+//   grid.x = columns * cosets, grid.y = proofs.
+//   in  : [col][n]           (+ blockIdx.y * in_batch_stride), optionally read through a bit-reversal
+//   pre : optional per-coset scale table [coset][n] applied on load (coset shift powers)
+//   out : [col][cosets * n]  block `out_block[coset]` of the column, optionally written through a bit-reversal,
+//         optionally multiplied by post[coset][i] (natural index i) or the scalar post_scalar.
+struct NttArgs {
+    const u64* in;
+    u64* out;
+    const u64* tw;     // w^k, k < n_max/2, for the forward or inverse root
+    const u64* pre;    // [cosets][n] or null
+    const u64* post;   // [cosets][n] or null (indexed by natural output index; needs bitrev_out)
+    u64 post_scalar;   // applied when post == null (1 = none)
+    size_t in_col_stride, out_col_stride, in_batch_stride, out_batch_stride;
+    int logn, log_nmax, cosets;
+    int bitrev_in, bitrev_out;
+    int in_coset_blocks;  // 1: input column holds `cosets` blocks of n (quotient inverse); 0: one block shared by all cosets
+    u32 block_of_coset[8];
+};
+
+__global__ __launch_bounds__(1024) void k_ntt_lds(NttArgs a) {
+    extern __shared__ __align__(16) u64 lds[];
+    const int logn = a.logn;
+    const u32 n = 1u << logn;
+    const u32 col = blockIdx.x / a.cosets, coset = blockIdx.x % a.cosets;
+    const u32 blk = a.block_of_coset[coset];
+    const u64* in = a.in + (size_t)blockIdx.y * a.in_batch_stride + (size_t)col * a.in_col_stride + (a.in_coset_blocks ? (size_t)blk * n : 0);
+    u64* out = a.out + (size_t)blockIdx.y * a.out_batch_stride + (size_t)col * a.out_col_stride + (size_t)blk * n;
+    const u64* pre = a.pre ? a.pre + (size_t)coset * n : nullptr;
+    const u64* post = a.post ? a.post + (size_t)coset * n : nullptr;
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+        u64 v = in[i];  // coalesced read; the permutation happens on the LDS side
+        u32 dst = a.bitrev_in ? (__brev(i) >> (32 - logn)) : i;
+        if (pre) v = gl::mul(v, pre[dst]);
+        lds[dst] = v;
+    }
+    __syncthreads();
+    const int tw_shift = a.log_nmax - logn;
+    for (int s = logn - 1; s >= 0; s--) {
+        const u32 h = 1u << s;
+        for (u32 t = threadIdx.x; t < (n >> 1); t += blockDim.x) {
+            u32 pos = t & (h - 1);
+            u32 i = ((t >> s) << (s + 1)) | pos;
+            u64 x = lds[i], y = lds[i + h];
+            u64 w = a.tw[(size_t)(pos << (logn - 1 - s)) << tw_shift];
+            lds[i] = gl::add(x, y);
+            lds[i + h] = gl::mul(gl::sub(x, y), w);
+        }
+        __syncthreads();
+    }
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+        // write position i (coalesced); it receives the element whose natural index is i when bitrev_out
+        u32 src = a.bitrev_out ? (__brev(i) >> (32 - logn)) : i;
+        u64 v = lds[src];
+        if (post)
+            v = gl::mul(v, post[i]);
+        else if (a.post_scalar != 1)
+            v = gl::mul(v, a.post_scalar);
+        out[i] = v;
+    }
+}
+
+// table[j][i] = (base[j])^i  for i < n   (coset shift powers and their inverses, zeta powers, ...)
+__global__ void k_pow_table(u64* table, const u64* bases, u32 n, u64 scale) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 b = bases[blockIdx.y];
+    table[(size_t)blockIdx.y * n + i] = gl::mul(gl::pow(b, i), scale);
+}
+
+// quotient: combine the 8 per-coset residues r_j (each deg < n) into the 8 chunks t_c:
+//   t_c[i] = s^-c / 8 * sum_j w8^(-j c) r_j[i],  s = g^n.   r: [ch][8][n] (block rev3(j) = coset j), t: [ch*8 + c][n]
+__global__ void k_quotient_chunks_rev(const u64* __restrict__ r, u64* __restrict__ t, u32 n, size_t r_batch_stride, size_t t_batch_stride,
+                                  const u64* __restrict__ w8inv_pows /*[8]*/, const u64* __restrict__ scale /*[8]: s^-c/8*/) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 ch = blockIdx.z;
+    const u64* rr = r + (size_t)blockIdx.y * r_batch_stride + (size_t)ch * 8 * n + i;
+    u64 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = rr[(size_t)(__brev((u32)j) >> 29) * n];
+    u64* tt = t + (size_t)blockIdx.y * t_batch_stride + (size_t)ch * 8 * n + i;
+    for (int c = 0; c < 8; c++) {
+        u64 acc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc = gl::add(acc, gl::mul(v[j], w8inv_pows[(j * c) & 7]));
+        tt[(size_t)c * n] = gl::mul(acc, scale[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- witness
+struct WitnessArgs {
+    const p2::Op* ops;
+    const u32* level_offsets;
+    u32 num_levels, num_slots, n_inputs;
+    const u32* input_slots;   // [n_inputs] (shared by the batch)
+    const u64* input_values;  // [batch][n_inputs]
+    u64* values;              // [batch][num_slots]
+    const int32_t* lut_idx;   // [num_luts][65536] input value -> table index or -1
+    const u32* lut_pairs;     // flat: (out<<16 | in) per entry
+    const u32* lut_offsets;   // [num_luts+1]
+    u32* mult;                // [batch][total_lut_entries] multiplicity counters (zeroed by the caller)
+    size_t total_lut_entries;
+    int* status;              // [batch]
+};
+
+// One workgroup generates one witness: ops are pre-sorted into dependency levels; every level is a parallel
+// sweep of the workgroup with a barrier in between (the op descriptors are shared by all proofs, L2-resident).
+__global__ __launch_bounds__(1024) void k_witness(WitnessArgs a) {
+    __shared__ int s_status;
+    const u32 proof = blockIdx.x;
+    u64* val = a.values + (size_t)proof * a.num_slots;
+    u32* mult = a.mult + (size_t)proof * a.total_lut_entries;
+    if (threadIdx.x == 0) s_status = 0;
+    for (u32 i = threadIdx.x; i < a.num_slots; i += blockDim.x) val[i] = UNSET;
+    __syncthreads();
+    // PartialWitness::set_target: one thread walks the inputs so that duplicate targets are checked in order
+    if (threadIdx.x == 0) {
+        const u64* iv = a.input_values + (size_t)proof * a.n_inputs;
+        for (u32 i = 0; i < a.n_inputs; i++) {
+            u32 s = a.input_slots[i];
+            u64 v = iv[i];
+            if (v >= gl::P) s_status = 3;
+            if (val[s] == UNSET)
+                val[s] = v;
+            else if (val[s] != v)
+                s_status = 3;
+        }
+    }
+    __syncthreads();
+    for (u32 lv = 0; lv < a.num_levels; lv++) {
+        const u32 beg = a.level_offsets[lv], end = a.level_offsets[lv + 1];
+        for (u32 k = beg + threadIdx.x; k < end; k += blockDim.x) {
+            const p2::Op o = a.ops[k];
+            u64 r = 0;
+            int bad = 0;
+            if (o.kind == p2::OP_ARITH) {
+                u64 x = val[o.a], y = val[o.b], z = val[o.c];
+                if (x == UNSET || y == UNSET || z == UNSET)
+                    bad = 2;
+                else
+                    r = gl::add(gl::mul(gl::mul(x, y), o.k0), gl::mul(z, o.k1));
+            } else if (o.kind == p2::OP_CONST) {
+                r = o.k0;
+            } else if (o.kind == p2::OP_LOOKUP) {
+                u64 x = val[o.a];
+                if (x == UNSET) {
+                    bad = 2;
+                } else if (x >= 65536) {
+                    bad = 1;
+                } else {
+                    int32_t idx = a.lut_idx[(size_t)o.aux * 65536 + x];
+                    if (idx < 0) {
+                        bad = 1;
+                    } else {
+                        u32 e = a.lut_offsets[o.aux] + (u32)idx;
+                        r = a.lut_pairs[e] >> 16;
+                        atomicAdd(&mult[e], 1u);
+                    }
+                }
+            } else {
+                u64 x = val[o.a], y = val[o.b];
+                if (x == UNSET || y == UNSET)
+                    bad = 2;
+                else if (o.kind == p2::OP_EQ)
+                    r = x == y ? 1 : 0;
+                else
+                    r = x == y ? 0 : gl::inv(gl::sub(x, y));
+            }
+            if (!bad) {
+                u64 cur = val[o.out];
+                if (cur == UNSET)
+                    val[o.out] = r;
+                else if (cur != r)
+                    bad = 1;
+            }
+            if (bad) atomicMax(&s_status, bad == 1 ? 3 : 2);  // conflict (1) outranks missing input (2); remapped below
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.status[proof] = s_status == 3 ? 1 : s_status;
+}
+
+// wires[col][row] = value of the wire's partition (or 0 for unconnected wires)
+__global__ void k_fill_wires(const int32_t* __restrict__ wire_slot, const u64* __restrict__ values, u64* __restrict__ wires, size_t total /*cols*n*/,
+                             u32 num_slots, size_t wires_batch_stride, int* status) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int32_t s = wire_slot[idx];
+    u64 v = 0;
+    if (s >= 0) {
+        v = values[(size_t)blockIdx.y * num_slots + s];
+        if (v == UNSET) {
+            v = 0;
+            atomicMax(&status[blockIdx.y], 2);
+        }
+    }
+    wires[(size_t)blockIdx.y * wires_batch_stride + idx] = v;
+}
+
+struct LutRowsArgs {
+    const u32* lut_pairs;
+    const u32* lut_offsets;
+    const p2::LookupRows* rows;
+    const u32* num_lookups;
+    const u32* mult;
+    size_t total_lut_entries;
+    u64* wires;
+    size_t wires_batch_stride;
+    u32 n, num_luts;
+};
+// LookupTableGate rows (table stored upside down + multiplicities) and padding of each LUT's last LookupGate
+__global__ void k_lut_rows(LutRowsArgs a) {
+    u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+    u64* w = a.wires + (size_t)blockIdx.y * a.wires_batch_stride;
+    const u32* mult = a.mult + (size_t)blockIdx.y * a.total_lut_entries;
+    if (e < a.total_lut_entries) {
+        u32 l = 0;
+        while (l + 1 < a.num_luts && e >= a.lut_offsets[l + 1]) l++;
+        u32 slot = e - a.lut_offsets[l];
+        u32 row = a.rows[l].first_lut - slot / p2::LUT_SLOTS, s = slot % p2::LUT_SLOTS;
+        u32 pr = a.lut_pairs[e];
+        u64 m = mult[e];
+        if (slot == 0) m += (p2::LU_SLOTS - a.num_lookups[l] % p2::LU_SLOTS) % p2::LU_SLOTS;
+        w[(size_t)(3 * s) * a.n + row] = pr & 0xFFFF;
+        w[(size_t)(3 * s + 1) * a.n + row] = pr >> 16;
+        w[(size_t)(3 * s + 2) * a.n + row] = m;
+    }
+    // padding: one thread per (lut, slot) of the first 40*num_luts threads of block 0
+    if (blockIdx.x == 0 && threadIdx.x < p2::LU_SLOTS * a.num_luts) {
+        u32 l = threadIdx.x / p2::LU_SLOTS, slot = threadIdx.x % p2::LU_SLOTS;
+        u32 remaining = (p2::LU_SLOTS - a.num_lookups[l] % p2::LU_SLOTS) % p2::LU_SLOTS;
+        if (slot >= p2::LU_SLOTS - remaining) {
+            u32 pr = a.lut_pairs[a.lut_offsets[l]];
+            u32 row = a.rows[l].last_lut - 1;
+            w[(size_t)(2 * slot) * a.n + row] = pr & 0xFFFF;
+            w[(size_t)(2 * slot + 1) * a.n + row] = pr >> 16;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- challenger
+// Per-proof Fiat-Shamir state kept in global memory between stages.
+struct ChalState {
+    u64 state[12];
+    u64 in[8];
+    u64 out[8];
+    u32 in_len, out_len;
+};
+struct DevChallenger {
+    ChalState s;
+    __device__ void duplexing() {
+        for (u32 i = 0; i < s.in_len; i++) s.state[i] = s.in[i];
+        s.in_len = 0;
+        gl::poseidon(s.state);
+        for (int i = 0; i < 8; i++) s.out[i] = s.state[i];
+        s.out_len = 8;
+    }
+    __device__ void observe(u64 x) {
+        s.out_len = 0;
+        s.in[s.in_len++] = x;
+        if (s.in_len == 8) duplexing();
+    }
+    __device__ u64 challenge() {
+        if (s.in_len != 0 || s.out_len == 0) duplexing();
+        return s.out[--s.out_len];
+    }
+};
+
+// Challenge block per proof (u64 words)
+enum ChalSlot {
+    CH_BETAS = 0,      // 2
+    CH_GAMMAS = 2,     // 2
+    CH_DELTAS = 4,     // 8
+    CH_ALPHAS = 12,    // 2
+    CH_ZETA = 14,      // 2
+    CH_FRI_ALPHA = 16, // 2
+    CH_FRI_BETAS = 18, // 2 * up to 8 rounds
+    CH_POW = 34,       // 1
+    CH_QUERY = 36,     // 28 (up to 64)
+    CH_WORDS = 100
+};
+
+struct ChalArgs {
+    ChalState* st;        // [batch]
+    u64* chal;            // [batch][CH_WORDS]
+    const u64* observe;   // data to observe: per proof `observe_len` words at stride observe_stride
+    size_t observe_stride;
+    u32 observe_len;
+    u32 batch;
+    u32 stage;            // see k_challenger
+    u32 aux;              // stage-specific (fri round, #queries, has_lookup)
+    u64 mod;              // query index modulus
+    const u64* digest;    // circuit digest (stage 0)
+    int* status;
+};
+// stage 0: init; observe circuit digest, pi hash (0^4), wires cap; betas, gammas, deltas
+// stage 1: observe zs cap; alphas            stage 2: observe quotient cap; zeta
+// stage 3: observe openings; fri_alpha       stage 4: observe FRI cap (round aux); beta
+// stage 5: observe final poly                stage 6: observe pow witness; response; query indices
+__global__ void k_challenger(ChalArgs a) {
+    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.batch) return;
+    DevChallenger c;
+    u64* ch = a.chal + (size_t)p * CH_WORDS;
+    if (a.stage == 0) {
+        for (int i = 0; i < 12; i++) c.s.state[i] = 0;
+        c.s.in_len = c.s.out_len = 0;
+        for (int i = 0; i < 4; i++) c.observe(a.digest[i]);
+        for (int i = 0; i < 4; i++) c.observe(0);
+    } else {
+        c.s = a.st[p];
+    }
+    const u64* ob = a.observe + (size_t)p * a.observe_stride;
+    if (a.stage == 6) {
+        c.observe(ch[CH_POW]);
+        (void)c.challenge();
+        for (u32 q = 0; q < a.aux; q++) ch[CH_QUERY + q] = c.challenge() % a.mod;
+        a.st[p] = c.s;
+        return;
+    }
+    for (u32 i = 0; i < a.observe_len; i++) c.observe(ob[i]);
+    if (a.stage == 0) {
+        for (int i = 0; i < 2; i++) ch[CH_BETAS + i] = c.challenge();
+        for (int i = 0; i < 2; i++) ch[CH_GAMMAS + i] = c.challenge();
+        if (a.aux) {
+            for (int i = 0; i < 2; i++) ch[CH_DELTAS + i] = ch[CH_BETAS + i];
+            for (int i = 0; i < 2; i++) ch[CH_DELTAS + 2 + i] = ch[CH_GAMMAS + i];
+            for (int i = 0; i < 4; i++) ch[CH_DELTAS + 4 + i] = c.challenge();
+        }
+    } else if (a.stage == 1) {
+        for (int i = 0; i < 2; i++) ch[CH_ALPHAS + i] = c.challenge();
+    } else if (a.stage == 2) {
+        u64 z0 = c.challenge(), z1 = c.challenge();
+        ch[CH_ZETA] = z0;
+        ch[CH_ZETA + 1] = z1;
+        // "Opening point is in the subgroup."
+        E2 zp = gl::exp_pow2(gl::e2(z0, z1), (int)a.aux);
+        if (zp.a == 1 && zp.b == 0) atomicMax(&a.status[p], 3);
+    } else if (a.stage == 3) {
+        ch[CH_FRI_ALPHA] = c.challenge();
+        ch[CH_FRI_ALPHA + 1] = c.challenge();
+    } else if (a.stage == 4) {
+        ch[CH_FRI_BETAS + 2 * a.aux] = c.challenge();
+        ch[CH_FRI_BETAS + 2 * a.aux + 1] = c.challenge();
+    }
+    a.st[p] = c.s;
+}
+
+// Proof-of-work grinding: smallest witness w such that the duplex response has >= pow_bits leading zeros.
+// grid.x workgroups of 256 candidates each per proof (grid.y); a workgroup whose whole range lies above the
+// best witness found so far exits at once.
+__global__ __launch_bounds__(256) void k_pow(const ChalState* st, u64* chal, int pow_bits, unsigned long long* best /*[batch]*/) {
+    const u32 p = blockIdx.y;
+    u64 cand = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long cur = *((volatile unsigned long long*)&best[p]);
+    if (cur < (u64)blockIdx.x * blockDim.x) return;
+    DevChallenger c;
+    c.s = st[p];
+    c.observe(cand);
+    u64 resp = c.challenge();
+    if ((resp >> (64 - pow_bits)) == 0) atomicMin(&best[p], (unsigned long long)cand);
+}
+__global__ void k_pow_finish(u64* chal, const unsigned long long* best, u32 batch, int* status) {
+    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= batch) return;
+    chal[(size_t)p * CH_WORDS + CH_POW] = best[p];
+    if (best[p] == ~0ull) atomicMax(&status[p], 4);
+}
+
+// ------------------------------------------------------------------------------------------- block scans
+// Inclusive scan of 1024 per-thread partials held in LDS (Hillis-Steele, 10 steps); OP is gl::add or gl::mul.
+template <bool MUL>
+__device__ __forceinline__ u64 block_scan_inclusive(u64 v, u64* lds) {
+    const u32 t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (u32 off = 1; off < blockDim.x; off <<= 1) {
+        u64 x = lds[t];
+        u64 y = t >= off ? lds[t - off] : (MUL ? 1 : 0);
+        __syncthreads();
+        lds[t] = MUL ? gl::mul(x, y) : gl::add(x, y);
+        __syncthreads();
+    }
+    return lds[t];
+}
+
+// ------------------------------------------------------------------------------------------- permutation argument
+// q[ch][chunk][row] = prod_{j in chunk}(w_j + beta*k_j*x + gamma) / prod_{j in chunk}(w_j + beta*sigma_j + gamma)
+__global__ void k_perm_chunks(const u64* __restrict__ wires, size_t wires_batch_stride, const u64* __restrict__ sigmas, const u64* __restrict__ k_is,
+                              const u64* __restrict__ subgroup, const u64* __restrict__ chal, u64* __restrict__ q, size_t q_batch_stride, u32 n,
+                              u32 num_routed, u32 chunk_size, u32 num_chunks) {
+    u32 row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    u32 chunk = blockIdx.z % num_chunks, ch = blockIdx.z / num_chunks;
+    const u64* cw = chal + (size_t)blockIdx.y * CH_WORDS;
+    u64 beta = cw[CH_BETAS + ch], gamma = cw[CH_GAMMAS + ch];
+    const u64* w = wires + (size_t)blockIdx.y * wires_batch_stride;
+    u64 bx = gl::mul(beta, subgroup[row]);
+    u64 num = 1, den = 1;
+    u32 j1 = min(num_routed, (chunk + 1) * chunk_size);
+    for (u32 j = chunk * chunk_size; j < j1; j++) {
+        u64 wv = w[(size_t)j * n + row];
+        num = gl::mul(num, gl::add(gl::add(wv, gl::mul(bx, k_is[j])), gamma));
+        den = gl::mul(den, gl::add(gl::add(wv, gl::mul(beta, sigmas[(size_t)j * n + row])), gamma));
+    }
+    q[(size_t)blockIdx.y * q_batch_stride + ((size_t)ch * num_chunks + chunk) * n + row] = gl::mul(num, gl::inv(den));
+}
+
+// Z and partial products from the chunk quotients.  One workgroup per (proof, challenge); rows are split into
+// 1024 contiguous segments, a workgroup-wide multiplicative scan links the segments.
+//   zs layout: [Z_0, Z_1, pp(ch0) 0..npp, pp(ch1) 0..npp, ...]   each [n]
+__global__ __launch_bounds__(1024) void k_perm_scan(const u64* __restrict__ q, size_t q_batch_stride, u64* __restrict__ zs, size_t zs_batch_stride, u32 n,
+                                                     u32 num_chunks, u32 num_challenges) {
+    __shared__ u64 lds[1024];
+    const u32 ch = blockIdx.x, t = threadIdx.x;
+    const u64* qq = q + (size_t)blockIdx.y * q_batch_stride + (size_t)ch * num_chunks * n;
+    u64* z = zs + (size_t)blockIdx.y * zs_batch_stride + (size_t)ch * n;
+    u64* pp = zs + (size_t)blockIdx.y * zs_batch_stride + ((size_t)num_challenges + (size_t)ch * (num_chunks - 1)) * n;
+    const u32 per = (n + blockDim.x - 1) / blockDim.x;
+    const u32 r0 = min(n, t * per), r1 = min(n, r0 + per);
+    u64 prod = 1;
+    for (u32 r = r0; r < r1; r++)
+        for (u32 c = 0; c < num_chunks; c++) prod = gl::mul(prod, qq[(size_t)c * n + r]);
+    u64 incl = block_scan_inclusive<true>(prod, lds);
+    // exclusive prefix = product of all earlier segments
+    u64 acc = t == 0 ? 1 : lds[t - 1];
+    (void)incl;
+    for (u32 r = r0; r < r1; r++) {
+        z[r] = acc;
+        for (u32 c = 0; c < num_chunks; c++) {
+            acc = gl::mul(acc, qq[(size_t)c * n + r]);
+            if (c + 1 < num_chunks) pp[(size_t)c * n + r] = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- lookup argument
+struct LookupArgs {
+    const u64* wires;
+    size_t wires_batch_stride;
+    const u64* chal;
+    u64* zs;  // base of the zs batch
+    size_t zs_batch_stride;
+    u64* tmp;  // [batch][ch][num_sldc + 1][n] scratch: per-row partial sums S_k and RE terms
+    size_t tmp_batch_stride;
+    const p2::LookupRows* rows;
+    u32 n, num_luts, num_sldc, lut_deg, lu_deg, num_challenges, zs_lookup_col0;  // first lookup column in zs
+};
+// phase 1: per (row, partial poly k): S_k[row] = sum over the poly's slots of mult/(alpha - combo)  (LUT rows)
+//          or  -sum 1/(alpha - combo)  (LookupGate rows); k == num_sldc: RE row term c[row] = sum_s combo_B[s] delta^(25-s)
+__global__ void k_lookup_terms(LookupArgs a) {
+    u32 row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.n) return;
+    u32 k = blockIdx.z % (a.num_sldc + 1), ch = blockIdx.z / (a.num_sldc + 1);
+    // which LUT (if any) owns this row?
+    int kind = 0;  // 1 = LUT row, 2 = LU row
+    for (u32 l = 0; l < a.num_luts; l++) {
+        p2::LookupRows lr = a.rows[l];
+        if (row >= lr.last_lut && row <= lr.first_lut) kind = 1;
+        if (row >= lr.last_lu && row < lr.last_lut) kind = 2;
+    }
+    const u64* d = a.chal + (size_t)blockIdx.y * CH_WORDS + CH_DELTAS + 4 * ch;  // A, B, Alpha, Delta
+    const u64* w = a.wires + (size_t)blockIdx.y * a.wires_batch_stride + row;
+    u64 r = 0;
+    if (kind == 1 && k < a.num_sldc) {
+        u32 s1 = min(p2::LUT_SLOTS, (k + 1) * a.lut_deg);
+        for (u32 s = k * a.lut_deg; s < s1; s++) {
+            u64 combo = gl::add(w[(size_t)(3 * s) * a.n], gl::mul(d[0], w[(size_t)(3 * s + 1) * a.n]));
+            r = gl::add(r, gl::mul(w[(size_t)(3 * s + 2) * a.n], gl::inv(gl::sub(d[2], combo))));
+        }
+    } else if (kind == 2 && k < a.num_sldc) {
+        u32 s1 = min(p2::LU_SLOTS, (k + 1) * a.lu_deg);
+        for (u32 s = k * a.lu_deg; s < s1; s++) {
+            u64 combo = gl::add(w[(size_t)(2 * s) * a.n], gl::mul(d[0], w[(size_t)(2 * s + 1) * a.n]));
+            r = gl::sub(r, gl::inv(gl::sub(d[2], combo)));
+        }
+    } else if (kind == 1) {
+        for (u32 s = 0; s < p2::LUT_SLOTS; s++) {
+            u64 combo = gl::add(w[(size_t)(3 * s) * a.n], gl::mul(d[1], w[(size_t)(3 * s + 1) * a.n]));
+            r = gl::add(gl::mul(r, d[3]), combo);
+        }
+    }
+    a.tmp[(size_t)blockIdx.y * a.tmp_batch_stride + ((size_t)ch * (a.num_sldc + 1) + k) * a.n + row] = r;
+}
+// phase 2: one workgroup per (lut, challenge, proof): suffix scans over the LUT's rows [last_lu, first_lut].
+//   SLDC_k[row] = (sum_{r > row} T[r]) + sum_{k' <= k} S_k'[row],  T[r] = sum_k S_k[r]
+//   RE[row]     = sum_{r >= row, r in LUT rows} c[r] * D^(r-row),  D = delta^26
+__global__ __launch_bounds__(1024) void k_lookup_scan(LookupArgs a) {
+    __shared__ u64 lds[1024];
+    const u32 l = blockIdx.x, ch = blockIdx.z, t = threadIdx.x;
+    const p2::LookupRows lr = a.rows[l];
+    const u64* tmp = a.tmp + (size_t)blockIdx.y * a.tmp_batch_stride + (size_t)ch * (a.num_sldc + 1) * a.n;
+    u64* zl = a.zs + (size_t)blockIdx.y * a.zs_batch_stride + ((size_t)a.zs_lookup_col0 + (size_t)ch * (a.num_sldc + 1)) * a.n;  // [RE, SLDC_0..]
+    const u64* d = a.chal + (size_t)blockIdx.y * CH_WORDS + CH_DELTAS + 4 * ch;
+    // rows processed top-down: position i = first_lut - row, i in [0, total)
+    const u32 total = lr.first_lut - lr.last_lu + 1;
+    const u32 per = (total + blockDim.x - 1) / blockDim.x;
+    const u32 i0 = min(total, t * per), i1 = min(total, i0 + per);
+    // ---- SLDC: additive scan of row totals
+    u64 seg = 0;
+    for (u32 i = i0; i < i1; i++) {
+        u32 row = lr.first_lut - i;
+        for (u32 k = 0; k < a.num_sldc; k++) seg = gl::add(seg, tmp[(size_t)k * a.n + row]);
+    }
+    block_scan_inclusive<false>(seg, lds);
+    u64 acc = t == 0 ? 0 : lds[t - 1];
+    for (u32 i = i0; i < i1; i++) {
+        u32 row = lr.first_lut - i;
+        for (u32 k = 0; k < a.num_sldc; k++) {
+            acc = gl::add(acc, tmp[(size_t)k * a.n + row]);
+            zl[(size_t)(1 + k) * a.n + row] = acc;
+        }
+    }
+    __syncthreads();
+    // ---- RE over the LUT rows only: re[row] = re[row+1]*D + c[row]; with i = first_lut - row:
+    //      re_i = sum_{m <= i} c_m D^(i-m)  =>  re_i = D^i * sum_{m<=i} c_m D^-m
+    const u32 lut_rows = lr.first_lut - lr.last_lut + 1;
+    const u32 per2 = (lut_rows + blockDim.x - 1) / blockDim.x;
+    const u32 j0 = min(lut_rows, t * per2), j1 = min(lut_rows, j0 + per2);
+    u64 D = gl::pow(d[3], p2::LUT_SLOTS), Dinv = gl::inv(D);
+    u64 dm = gl::pow(Dinv, j0), s2 = 0;
+    for (u32 i = j0; i < j1; i++) {
+        s2 = gl::add(s2, gl::mul(tmp[(size_t)a.num_sldc * a.n + (lr.first_lut - i)], dm));
+        dm = gl::mul(dm, Dinv);
+    }
+    block_scan_inclusive<false>(s2, lds);
+    u64 pre = t == 0 ? 0 : lds[t - 1];
+    dm = gl::pow(Dinv, j0);
+    u64 dp = gl::pow(D, j0);
+    for (u32 i = j0; i < j1; i++) {
+        pre = gl::add(pre, gl::mul(tmp[(size_t)a.num_sldc * a.n + (lr.first_lut - i)], dm));
+        zl[lr.first_lut - i] = gl::mul(pre, dp);
+        dm = gl::mul(dm, Dinv);
+        dp = gl::mul(dp, D);
+    }
+}
+
+}  // namespace p2k

@@ -1,0 +1,438 @@
+// Second half of the pipeline kernels: quotient (gate-constraint) evaluation, openings, FRI.
+#pragma once
+#include "kernels.h"
+
+namespace p2k {
+
+// ------------------------------------------------------------------------------------------- quotient
+struct QuotientArgs {
+    const u64* pre_lde;    // [ncc + R][8n]   constants | sigmas
+    const u64* wires_lde;  // [active][8n]
+    const u64* zs_lde;     // [zs_cols][8n]
+    size_t wires_batch_stride, zs_batch_stride;
+    const u64* chal;
+    const u64* xs;      // [8n] x at LDE position p (bit-reversed layout)
+    const u64* l0;      // [8n] L_0(x)
+    const u64* zh_inv;  // [8] indexed by coset j
+    const u64* k_is;
+    const u64* lut_polys_rows;  // unused
+    u64* out;                   // [batch][NC][8n]
+    size_t out_batch_stride;
+    u32 n, logn, rate_bits, R, ncc, nsel, nls, NC, npp, qdf, num_luts, nsldc, lut_deg, nlp;
+    u32 num_gates, num_gate_constraints;
+    u32 gate_kind[8], gate_sel[8], group_lo[8], group_hi[8];
+    u32 lut_last_row[8];  // last_lut row per LUT: RE there equals get_lut_poly (read from the zs VALUES)
+    const u64* zs_values;  // [zs_cols][n]
+    size_t zs_values_batch_stride;
+};
+
+struct AlphaAcc {
+    u64 acc[2], pw[2], alpha[2];
+    __device__ __forceinline__ void init(u64 a0, u64 a1) {
+        alpha[0] = a0;
+        alpha[1] = a1;
+        acc[0] = acc[1] = 0;
+        pw[0] = pw[1] = 1;
+    }
+    __device__ __forceinline__ void push(int i, u64 term) {  // term for challenge-independent position, alpha i
+        acc[i] = gl::add(acc[i], gl::mul(term, pw[i]));
+        pw[i] = gl::mul(pw[i], alpha[i]);
+    }
+    __device__ __forceinline__ void push_both(u64 term) {
+        push(0, term);
+        push(1, term);
+    }
+};
+
+// One thread per point of the LDE coset (bit-reversed position p); evaluates every constraint of
+// eval_vanishing_poly_base, folds them with both alphas and divides by Z_H.
+__global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
+    const u32 N = a.n << a.rate_bits;
+    const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const u32 lde_bits = a.logn + a.rate_bits;
+    // natural index i = rev(p); next = i + 2^rate_bits (mod N); its position
+    const u32 i_nat = __brev(p) >> (32 - lde_bits);
+    const u32 p_next = __brev((i_nat + (1u << a.rate_bits)) & (N - 1)) >> (32 - lde_bits);
+    const u32 coset = i_nat & ((1u << a.rate_bits) - 1);
+    const u64* cw = a.chal + (size_t)blockIdx.y * CH_WORDS;
+    const u64* W = a.wires_lde + (size_t)blockIdx.y * a.wires_batch_stride + p;
+    const u64* Zs = a.zs_lde + (size_t)blockIdx.y * a.zs_batch_stride + p;
+    const u64* Zn = a.zs_lde + (size_t)blockIdx.y * a.zs_batch_stride + p_next;
+    const u64* C = a.pre_lde + p;
+    const u64* S = a.pre_lde + (size_t)a.ncc * N + p;
+    const u64 x = a.xs[p], l0 = a.l0[p];
+    AlphaAcc A;
+    A.init(cw[CH_ALPHAS], cw[CH_ALPHAS + 1]);
+    // plonky2 orders the terms [z1 (NC), partial products (NC*(npp+1)), lookups (NC*..), gates]; the position of a
+    // term fixes its alpha power, so walk them in exactly that order.
+    for (u32 i = 0; i < a.NC; i++) A.push_both(gl::mul(l0, gl::sub(Zs[(size_t)i * N], 1)));
+    for (u32 i = 0; i < a.NC; i++) {
+        const u64 beta = cw[CH_BETAS + i], gamma = cw[CH_GAMMAS + i];
+        const u64 bx = gl::mul(beta, x);
+        for (u32 chunk = 0; chunk <= a.npp; chunk++) {
+            u64 num = 1, den = 1;
+            u32 j1 = min(a.R, (chunk + 1) * a.qdf);
+            for (u32 j = chunk * a.qdf; j < j1; j++) {
+                u64 wv = W[(size_t)j * N];
+                num = gl::mul(num, gl::add(gl::add(wv, gl::mul(bx, a.k_is[j])), gamma));
+                den = gl::mul(den, gl::add(gl::add(wv, gl::mul(beta, S[(size_t)j * N])), gamma));
+            }
+            u64 prev = chunk == 0 ? Zs[(size_t)i * N] : Zs[(size_t)(a.NC + i * a.npp + chunk - 1) * N];
+            u64 next = chunk == a.npp ? Zn[(size_t)i * N] : Zs[(size_t)(a.NC + i * a.npp + chunk) * N];
+            A.push_both(gl::sub(gl::mul(prev, num), gl::mul(next, den)));
+        }
+    }
+    if (a.nlp) {
+        const u64* sel = C + (size_t)a.nsel * N;  // TransSre, TransLdc, InitSre, LastLdc, StartEnd..
+        const u64 s_sre = sel[0], s_ldc = sel[(size_t)1 * N], s_init = sel[(size_t)2 * N], s_last = sel[(size_t)3 * N];
+        const u32 lk0 = a.NC * (1 + a.npp);
+        for (u32 i = 0; i < a.NC; i++) {
+            const u64* d = cw + CH_DELTAS + 4 * i;
+            const u64 dA = d[0], dB = d[1], dAl = d[2], dD = d[3];
+            const u64* lz = Zs + (size_t)(lk0 + i * a.nlp) * N;
+            const u64* lzn = Zn + (size_t)(lk0 + i * a.nlp) * N;
+            const u64 z_re = lz[0], next_z_re = lzn[0];
+            A.push_both(gl::mul(s_last, lz[(size_t)a.nsldc * N]));
+            A.push_both(gl::mul(s_init, lz[(size_t)1 * N]));
+            A.push_both(gl::mul(s_init, z_re));
+            const u64* zv = a.zs_values + (size_t)blockIdx.y * a.zs_values_batch_stride + (size_t)(lk0 + i * a.nlp) * a.n;
+            for (u32 l = 0; l < a.num_luts; l++) A.push_both(gl::mul(sel[(size_t)(4 + l) * N], gl::sub(z_re, zv[a.lut_last_row[l]])));
+            u64 cur = next_z_re;
+            for (u32 s = 0; s < p2::LUT_SLOTS; s++) cur = gl::add(gl::mul(cur, dD), gl::add(W[(size_t)(3 * s) * N], gl::mul(dB, W[(size_t)(3 * s + 1) * N])));
+            A.push_both(gl::mul(s_sre, gl::sub(z_re, cur)));
+            for (u32 poly = 0; poly < a.nsldc; poly++) {
+                // f_k = alpha - combo_k for this poly's slots; prod = prod f_k, sum = sum_k (c_k) prod_{m != k} f_m
+                u64 f[8], mlt[8];
+                u32 a0 = poly * a.lut_deg, a1 = min(p2::LUT_SLOTS, (poly + 1) * a.lut_deg), cnt = a1 - a0;
+                for (u32 k = 0; k < cnt; k++) {
+                    u32 s = a0 + k;
+                    f[k] = gl::sub(dAl, gl::add(W[(size_t)(3 * s) * N], gl::mul(dA, W[(size_t)(3 * s + 1) * N])));
+                    mlt[k] = W[(size_t)(3 * s + 2) * N];
+                }
+                u64 lut_prod = 1, lut_sum = 0;
+                for (u32 k = 0; k < cnt; k++) {  // incremental: sum' = sum*f_k + c_k*prod ; prod' = prod*f_k
+                    lut_sum = gl::add(gl::mul(lut_sum, f[k]), gl::mul(mlt[k], lut_prod));
+                    lut_prod = gl::mul(lut_prod, f[k]);
+                }
+                u32 b0 = poly * (a.qdf - 1), b1 = min(p2::LU_SLOTS, (poly + 1) * (a.qdf - 1));
+                u64 lu_prod = 1, lu_sum = 0;
+                for (u32 s = b0; s < b1; s++) {
+                    u64 fk = gl::sub(dAl, gl::add(W[(size_t)(2 * s) * N], gl::mul(dA, W[(size_t)(2 * s + 1) * N])));
+                    lu_sum = gl::add(gl::mul(lu_sum, fk), lu_prod);
+                    lu_prod = gl::mul(lu_prod, fk);
+                }
+                u64 prev = poly == 0 ? lzn[(size_t)a.nsldc * N] : lz[(size_t)poly * N];
+                u64 diff = gl::sub(lz[(size_t)(1 + poly) * N], prev);
+                A.push_both(gl::mul(s_sre, gl::sub(gl::mul(lut_prod, diff), lut_sum)));
+                A.push_both(gl::mul(s_ldc, gl::add(gl::mul(lu_prod, diff), lu_sum)));
+            }
+        }
+    }
+    // gate constraints: constraint slot k collects every gate's k-th constraint times the gate's filter
+    {
+        const u64* gc = C + (size_t)(a.nsel + a.nls) * N;
+        const u64 c0 = gc[0], c1 = gc[(size_t)1 * N];
+        u64 f_arith = 0, f_const = 0, f_pi = 0;
+        for (u32 g = 0; g < a.num_gates; g++) {
+            u32 kind = a.gate_kind[g];
+            if (kind != p2::G_ARITHMETIC && kind != p2::G_CONSTANT && kind != p2::G_PUBLIC_INPUT) continue;
+            u64 s = C[(size_t)a.gate_sel[g] * N], filter = 1;
+            for (u32 j = a.group_lo[g]; j < a.group_hi[g]; j++)
+                if (j != g) filter = gl::mul(filter, gl::sub(j, s));
+            if (a.nsel > 1) filter = gl::mul(filter, gl::sub(p2::UNUSED_SELECTOR, s));
+            if (kind == p2::G_ARITHMETIC) f_arith = filter;
+            if (kind == p2::G_CONSTANT) f_const = filter;
+            if (kind == p2::G_PUBLIC_INPUT) f_pi = filter;
+        }
+        for (u32 k = 0; k < a.num_gate_constraints; k++) {
+            u64 term = 0;
+            if (k < p2::ARITH_OPS && f_arith) {
+                u64 m0 = W[(size_t)(4 * k) * N], m1 = W[(size_t)(4 * k + 1) * N], ad = W[(size_t)(4 * k + 2) * N], o = W[(size_t)(4 * k + 3) * N];
+                term = gl::mul(f_arith, gl::sub(o, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1))));
+            }
+            if (k < 2 && f_const) term = gl::add(term, gl::mul(f_const, gl::sub(k == 0 ? c0 : c1, W[(size_t)k * N])));
+            if (k < 4 && f_pi) term = gl::add(term, gl::mul(f_pi, W[(size_t)k * N]));
+            A.push_both(term);
+        }
+    }
+    const u64 zi = a.zh_inv[coset];
+    u64* out = a.out + (size_t)blockIdx.y * a.out_batch_stride + p;
+    out[0] = gl::mul(A.acc[0], zi);
+    out[(size_t)N] = gl::mul(A.acc[1], zi);
+}
+
+// ------------------------------------------------------------------------------------------- openings
+// pows[k][i] = z_k^i (extension), k = 0: zeta, 1: g*zeta, 2: 1/zeta, 3: 1/(g*zeta).  layout [k][2][n] (c0 | c1)
+__global__ void k_zeta_pows(const u64* chal, u64* pows, size_t pows_batch_stride, u32 n, u64 g) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64* cw = chal + (size_t)blockIdx.y * CH_WORDS;
+    E2 z = gl::e2(cw[CH_ZETA], cw[CH_ZETA + 1]);
+    u32 k = blockIdx.z;
+    if (k & 1) z = gl::mul(z, g);
+    if (k & 2) z = gl::inv(z);
+    E2 r = gl::pow(z, i);
+    u64* o = pows + (size_t)blockIdx.y * pows_batch_stride + (size_t)k * 2 * n;
+    o[i] = r.a;
+    o[n + i] = r.b;
+}
+// out[col] = sum_i coeffs[col][i] * pw[i]   (extension result), one workgroup per (column, proof)
+__global__ __launch_bounds__(256) void k_eval_polys(const u64* __restrict__ coeffs, size_t coeffs_batch_stride, const u64* __restrict__ pw /*[2][n]*/,
+                                                     size_t pw_batch_stride, u32 n, u64* __restrict__ out /*[cols][2]*/, size_t out_batch_stride) {
+    __shared__ u64 la[256], lb[256];
+    const u64* c = coeffs + (size_t)blockIdx.y * coeffs_batch_stride + (size_t)blockIdx.x * n;
+    const u64* pa = pw + (size_t)blockIdx.y * pw_batch_stride;
+    u64 sa = 0, sb = 0;
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+        u64 v = c[i];
+        sa = gl::add(sa, gl::mul(v, pa[i]));
+        sb = gl::add(sb, gl::mul(v, pa[n + i]));
+    }
+    la[threadIdx.x] = sa;
+    lb[threadIdx.x] = sb;
+    __syncthreads();
+    for (u32 off = blockDim.x / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            la[threadIdx.x] = gl::add(la[threadIdx.x], la[threadIdx.x + off]);
+            lb[threadIdx.x] = gl::add(lb[threadIdx.x], lb[threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        u64* o = out + (size_t)blockIdx.y * out_batch_stride + 2 * (size_t)blockIdx.x;
+        o[0] = la[0];
+        o[1] = lb[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------- FRI
+// Batch description: for each polynomial of a FRI batch, where its coefficient column lives.
+struct PolyRef {
+    const u64* base;      // coefficient matrix of the oracle (proof 0)
+    size_t batch_stride;  // 0 for the shared preprocessed oracle
+    u32 col;
+    u32 pad;
+};
+// comp[b][k] = sum_j alpha^j f_{b,j}[k]   for the two FRI batches (b = 0: zeta, b = 1: g*zeta); output [b][2][n]
+__global__ __launch_bounds__(256) void k_fri_compose(const PolyRef* __restrict__ polys, u32 n0, u32 n1, const u64* chal, u32 n, u64* comp, size_t comp_batch_stride) {
+    u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const u64* cw = chal + (size_t)blockIdx.y * CH_WORDS;
+    const E2 alpha = gl::e2(cw[CH_FRI_ALPHA], cw[CH_FRI_ALPHA + 1]);
+    u64* o = comp + (size_t)blockIdx.y * comp_batch_stride;
+    u32 off = 0;
+    for (u32 b = 0; b < 2; b++) {
+        u32 cnt = b == 0 ? n0 : n1;
+        E2 acc = gl::e2(0, 0);
+        for (u32 j = cnt; j-- > 0;) {  // Horner: acc = acc*alpha + f_j[k]
+            const PolyRef pr = polys[off + j];
+            u64 v = pr.base ? pr.base[(size_t)blockIdx.y * pr.batch_stride + (size_t)pr.col * n + k] : 0;
+            acc = gl::mul(acc, alpha);
+            acc.a = gl::add(acc.a, v);
+        }
+        o[(size_t)(2 * b) * n + k] = acc.a;
+        o[(size_t)(2 * b + 1) * n + k] = acc.b;
+        off += cnt;
+    }
+}
+// Division of both compositions by (X - z_b), combination final = Q_0 * alpha^{n1} + Q_1.
+//   Q[k-1] = sum_{i >= k} comp[i] z^(i-k) = z^-k * sum_{i>=k} comp[i] z^i         (remainder dropped, Q[n-1] = 0)
+// One workgroup per proof; extension-field suffix scan over n coefficients.
+__global__ __launch_bounds__(1024) void k_fri_divide(const u64* comp, size_t comp_batch_stride, const u64* pows, size_t pows_batch_stride, const u64* chal,
+                                                      u32 n, u32 n1, u64* final_poly /*[2][n]*/, size_t final_batch_stride) {
+    __shared__ u64 la[1024], lb[1024];
+    const u32 t = threadIdx.x;
+    const u64* cw = chal + (size_t)blockIdx.x * CH_WORDS;
+    const E2 alpha = gl::e2(cw[CH_FRI_ALPHA], cw[CH_FRI_ALPHA + 1]);
+    const E2 shift = gl::pow(alpha, n1);
+    u64* fo = final_poly + (size_t)blockIdx.x * final_batch_stride;
+    const u32 per = (n + blockDim.x - 1) / blockDim.x;
+    // descending order: position d = n-1-i
+    const u32 d0 = min(n, t * per), d1 = min(n, d0 + per);
+    for (u32 b = 0; b < 2; b++) {
+        const u64* c = comp + (size_t)blockIdx.x * comp_batch_stride + (size_t)(2 * b) * n;
+        const u64* zp = pows + (size_t)blockIdx.x * pows_batch_stride + (size_t)b * 2 * n;         // z^i
+        const u64* zi = pows + (size_t)blockIdx.x * pows_batch_stride + (size_t)(2 + b) * 2 * n;   // z^-i
+        E2 seg = gl::e2(0, 0);
+        for (u32 d = d0; d < d1; d++) {
+            u32 i = n - 1 - d;
+            seg = gl::add(seg, gl::mul(gl::e2(c[i], c[n + i]), gl::e2(zp[i], zp[n + i])));
+        }
+        __syncthreads();
+        la[t] = seg.a;
+        lb[t] = seg.b;
+        __syncthreads();
+        for (u32 off = 1; off < blockDim.x; off <<= 1) {
+            u64 xa = la[t], xb = lb[t];
+            u64 ya = t >= off ? la[t - off] : 0, yb = t >= off ? lb[t - off] : 0;
+            __syncthreads();
+            la[t] = gl::add(xa, ya);
+            lb[t] = gl::add(xb, yb);
+            __syncthreads();
+        }
+        E2 acc = t == 0 ? gl::e2(0, 0) : gl::e2(la[t - 1], lb[t - 1]);
+        for (u32 d = d0; d < d1; d++) {
+            u32 i = n - 1 - d;  // acc = sum_{i' > i} comp[i'] z^i'  ->  Q[i] = acc * z^-(i+1)
+            E2 q = gl::e2(0, 0);
+            if (i + 1 < n) q = gl::mul(acc, gl::e2(zi[i + 1], zi[n + i + 1]));
+            if (b == 0) {
+                E2 s = gl::mul(q, shift);
+                fo[i] = s.a;
+                fo[n + i] = s.b;
+            } else {
+                fo[i] = gl::add(fo[i], q.a);
+                fo[n + i] = gl::add(fo[n + i], q.b);
+            }
+            acc = gl::add(acc, gl::mul(gl::e2(c[i], c[n + i]), gl::e2(zp[i], zp[n + i])));
+        }
+        __syncthreads();
+    }
+}
+// fold coefficients by beta: out[k] = sum_{i<arity} beta^i in[arity*k + i];  in/out: [2][len] component columns
+__global__ void k_fri_fold(const u64* in, size_t in_len, size_t in_batch_stride, u64* out, size_t out_len, size_t out_batch_stride, const u64* chal,
+                           u32 round, u32 arity) {
+    u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= out_len) return;
+    const u64* cw = chal + (size_t)blockIdx.y * CH_WORDS;
+    const E2 beta = gl::e2(cw[CH_FRI_BETAS + 2 * round], cw[CH_FRI_BETAS + 2 * round + 1]);
+    const u64* a = in + (size_t)blockIdx.y * in_batch_stride;
+    E2 acc = gl::e2(0, 0);
+    for (u32 i = arity; i-- > 0;) {
+        acc = gl::mul(acc, beta);
+        acc.a = gl::add(acc.a, a[(size_t)arity * k + i]);
+        acc.b = gl::add(acc.b, a[in_len + (size_t)arity * k + i]);
+    }
+    u64* o = out + (size_t)blockIdx.y * out_batch_stride;
+    o[k] = acc.a;
+    o[out_len + k] = acc.b;
+}
+
+// ------------------------------------------------------------------------------------------- proof assembly
+__device__ __forceinline__ void store_u64_bytes(uint8_t* p, u64 v) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (8 * i));
+}
+// copy `count` u64 words (src stride per proof) to byte offset `dst_off` of every proof
+__global__ void k_proof_copy(const u64* src, size_t src_batch_stride, u32 count, uint8_t* proofs, size_t proof_bytes, size_t dst_off) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    store_u64_bytes(proofs + (size_t)blockIdx.y * proof_bytes + dst_off + 8 * (size_t)i, src[(size_t)blockIdx.y * src_batch_stride + i]);
+}
+// strided variant: word i comes from src[i * elem_stride]  (component-column -> interleaved extension elements)
+__global__ void k_proof_copy_ext(const u64* src, size_t src_batch_stride, size_t comp_stride, u32 count, uint8_t* proofs, size_t proof_bytes, size_t dst_off) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const u64* s = src + (size_t)blockIdx.y * src_batch_stride;
+    uint8_t* d = proofs + (size_t)blockIdx.y * proof_bytes + dst_off + 16 * (size_t)i;
+    store_u64_bytes(d, s[i]);
+    store_u64_bytes(d + 8, s[comp_stride + i]);
+}
+
+// dst[i] (extension) = src[map[i]]
+__global__ void k_gather_ext(const u64* src, size_t src_batch_stride, const u32* map, u32 count, u64* dst, size_t dst_batch_stride) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const u64* s = src + (size_t)blockIdx.y * src_batch_stride + 2 * (size_t)map[i];
+    u64* d = dst + (size_t)blockIdx.y * dst_batch_stride + 2 * (size_t)i;
+    d[0] = s[0];
+    d[1] = s[1];
+}
+__global__ void k_proof_gather_ext(const u64* src, size_t src_batch_stride, const u32* map, u32 count, uint8_t* proofs, size_t proof_bytes, size_t dst_off) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const u64* s = src + (size_t)blockIdx.y * src_batch_stride + 2 * (size_t)map[i];
+    uint8_t* d = proofs + (size_t)blockIdx.y * proof_bytes + dst_off + 16 * (size_t)i;
+    store_u64_bytes(d, s[0]);
+    store_u64_bytes(d + 8, s[1]);
+}
+// component columns [2][len] -> interleaved (c0, c1) pairs
+__global__ void k_interleave_ext(const u64* src, size_t len, size_t src_batch_stride, u64* dst, size_t dst_batch_stride) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const u64* s = src + (size_t)blockIdx.y * src_batch_stride;
+    u64* d = dst + (size_t)blockIdx.y * dst_batch_stride;
+    d[2 * (size_t)i] = s[i];
+    d[2 * (size_t)i + 1] = s[len + i];
+}
+// publish the per-proof status; a failed proof's slot is zeroed
+__global__ void k_finish(const int* status, int* status_out, uint8_t* proofs, size_t proof_bytes, u32 batch) {
+    u32 p = blockIdx.y;
+    int st = status[p];
+    if (blockIdx.x == 0 && threadIdx.x == 0) status_out[p] = st;
+    if (st != 0) {
+        size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < proof_bytes) proofs[(size_t)p * proof_bytes + i] = 0;
+    }
+}
+
+struct QueryOracle {
+    const u64* lde;        // [cols][N] column-major (active cols only)
+    size_t lde_batch_stride;
+    const u64* digests;    // level 0 .. cap-1 consecutively: level l starts at dig_level_off[l] (in u64)
+    size_t dig_batch_stride;
+    u32 cols, active_cols;
+};
+struct QueryArgs {
+    QueryOracle oracles[4];
+    u32 lde_bits, cap_height, num_queries;
+    // FRI rounds
+    u32 num_rounds;
+    u32 arity_bits[8];
+    const u64* fri_vals[8];  // [2][len_r] component columns, bit-reversed order
+    size_t fri_vals_batch_stride[8];
+    u32 fri_bits[8];  // log2(len_r)
+    const u64* fri_digests[8];
+    size_t fri_dig_batch_stride[8];
+    const u64* chal;
+    uint8_t* proofs;
+    size_t proof_bytes, queries_off, query_bytes;
+};
+// digest level offsets inside one tree buffer: level l (l = 0 leaves) holds (num_leaves >> l) digests
+__device__ __forceinline__ size_t level_off(u32 height_bits, u32 l) {
+    // sum_{k<l} 4 * 2^(h-k) = 4 * (2^(h+1) - 2^(h-l+1))
+    return 4 * (((size_t)2 << height_bits) - ((size_t)2 << (height_bits - l)));
+}
+// One workgroup per (query, proof): serialises FriQueryRound { initial_trees_proof, steps }.
+__global__ __launch_bounds__(256) void k_write_queries(QueryArgs a) {
+    const u32 q = blockIdx.x, p = blockIdx.y;
+    const u64* cw = a.chal + (size_t)p * CH_WORDS;
+    u32 x_index = (u32)cw[CH_QUERY + q];
+    uint8_t* out = a.proofs + (size_t)p * a.proof_bytes + a.queries_off + (size_t)q * a.query_bytes;
+    const u32 nsib = a.lde_bits - a.cap_height;
+    for (int o = 0; o < 4; o++) {
+        const QueryOracle& O = a.oracles[o];
+        const size_t N = (size_t)1 << a.lde_bits;
+        const u64* lde = O.lde + (size_t)p * O.lde_batch_stride;
+        for (u32 c = threadIdx.x; c < O.cols; c += blockDim.x) store_u64_bytes(out + 8 * (size_t)c, c < O.active_cols ? lde[(size_t)c * N + x_index] : 0);
+        out += 8 * (size_t)O.cols;
+        if (threadIdx.x == 0) out[0] = (uint8_t)nsib;
+        out += 1;
+        const u64* dg = O.digests + (size_t)p * O.dig_batch_stride;
+        for (u32 t = threadIdx.x; t < nsib * 4; t += blockDim.x) {
+            u32 l = t >> 2;
+            store_u64_bytes(out + 8 * (size_t)t, dg[level_off(a.lde_bits, l) + 4 * (size_t)((x_index >> l) ^ 1) + (t & 3)]);
+        }
+        out += 32 * (size_t)nsib;
+    }
+    for (u32 r = 0; r < a.num_rounds; r++) {
+        const u32 ab = a.arity_bits[r], arity = 1u << ab;
+        x_index >>= ab;
+        const size_t len = (size_t)1 << a.fri_bits[r];
+        const u64* v = a.fri_vals[r] + (size_t)p * a.fri_vals_batch_stride[r];
+        for (u32 e = threadIdx.x; e < 2 * arity; e += blockDim.x)
+            store_u64_bytes(out + 8 * (size_t)e, v[(size_t)(e & 1) * len + (size_t)x_index * arity + (e >> 1)]);
+        out += 16 * (size_t)arity;
+        const u32 tree_bits = a.fri_bits[r] - ab, ns = tree_bits - a.cap_height;
+        if (threadIdx.x == 0) out[0] = (uint8_t)ns;
+        out += 1;
+        const u64* dg = a.fri_digests[r] + (size_t)p * a.fri_dig_batch_stride[r];
+        for (u32 t = threadIdx.x; t < ns * 4; t += blockDim.x) {
+            u32 l = t >> 2;
+            store_u64_bytes(out + 8 * (size_t)t, dg[level_off(tree_bits, l) + 4 * (size_t)((x_index >> l) ^ 1) + (t & 3)]);
+        }
+        out += 32 * (size_t)ns;
+    }
+}
+
+}  // namespace p2k

@@ -1,0 +1,1007 @@
+// GPU half of the C ABI (include/p2aes.h): p2_circuit_load, p2_prove_batch(_device), debug reads, primitives.
+// Replaces `CircuitData::prove(pw)` (reference call sites: SURVEY.md A.2) with a sequence of HIP kernels on one
+// stream per circuit handle; no host synchronisation between stages (Fiat-Shamir runs in a device kernel).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "capi_common.h"
+#include "kernels.h"
+#include "kernels2.h"
+
+using namespace p2;
+using namespace p2k;
+
+#define HIPCHECK(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                       \
+            return P2_ERR_HIP;                                                                  \
+        }                                                                                       \
+    } while (0)
+
+struct Tree {
+    u64* dig = nullptr;  // [batch][4 * 2^(bits+1)]
+    u32 bits = 0;        // log2(#leaves)
+    size_t stride() const { return (size_t)8 << bits; }
+};
+
+struct p2_circuit {
+    Circuit c;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    size_t n = 0, N = 0;
+    u32 logn = 0, lde_bits = 0, active_wires = 0;
+    size_t pbytes = 0;
+    std::vector<u32> arities;
+    // ---- static device data
+    Op* d_ops = nullptr;
+    u32* d_level_offsets = nullptr;
+    int32_t *d_wire_slot = nullptr, *d_lut_idx = nullptr;
+    u32 *d_lut_pairs = nullptr, *d_lut_offsets = nullptr, *d_num_lookups = nullptr;
+    LookupRows* d_lookup_rows = nullptr;
+    size_t total_lut_entries = 0;
+    u64 *d_sigmas = nullptr, *d_k_is = nullptr, *d_subgroup = nullptr;
+    u64 *d_tw_fwd = nullptr, *d_tw_inv = nullptr;  // w^k / w^-k for k < n_max/2, n_max = n
+    u64* d_shift_pows[9] = {nullptr};              // per FRI round r (0 = main LDE): [8][n_r] (s_r w^j)^i
+    u64* d_shift_inv_pows = nullptr;               // [8][n] (g w^j)^-i / n   (quotient inverse)
+    u64 *d_xs = nullptr, *d_l0 = nullptr, *d_zh_inv = nullptr, *d_w8inv = nullptr, *d_qscale = nullptr;
+    u64 *d_pre_coeffs = nullptr, *d_pre_lde = nullptr;
+    Tree pre_tree;
+    u64* d_digest = nullptr;  // circuit digest (4)
+    std::vector<u64> verifier_data;
+    PolyRef* d_polyrefs = nullptr;
+    u32 n_b0 = 0, n_b1 = 0;
+    u32 *d_map_obs = nullptr, *d_map_ser = nullptr;
+    u32 n_obs = 0, n_ser = 0, ev_count = 0;
+    // ---- per-chunk workspace
+    size_t chunk = 0;
+    u32 ws_inputs = 0;
+    u32* d_input_slots = nullptr;
+    u64* d_input_values = nullptr;
+    u64* d_values = nullptr;
+    u32* d_mult = nullptr;
+    int* d_status = nullptr;
+    u64 *d_wires = nullptr, *d_wcoef = nullptr, *d_wlde = nullptr;
+    u64 *d_zs = nullptr, *d_zcoef = nullptr, *d_zlde = nullptr, *d_permq = nullptr, *d_lktmp = nullptr;
+    u64 *d_qvals = nullptr, *d_qres = nullptr, *d_qcoef = nullptr, *d_qlde = nullptr;
+    Tree wtree, ztree, qtree;
+    ChalState* d_chal_state = nullptr;
+    u64* d_chal = nullptr;
+    u64 *d_pows = nullptr, *d_ev = nullptr, *d_obs = nullptr, *d_comp = nullptr;
+    u64* d_fri_coef[9] = {nullptr};  // [2][n_r]
+    u64* d_fri_vals[9] = {nullptr};  // [2][8 n_r]
+    Tree fri_tree[9];
+    unsigned long long* d_pow_best = nullptr;
+    uint8_t* d_proofs = nullptr;
+    // timing
+    bool timing_on = false;
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+    std::map<std::string, std::pair<float, u32>> times;
+    std::vector<void*> allocs;
+    std::mutex mu;
+};
+
+template <class T>
+static int dalloc(p2_circuit* C, T** p, size_t count) {
+    void* q = nullptr;
+    HIPCHECK(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    C->allocs.push_back(q);
+    *p = (T*)q;
+    return 0;
+}
+template <class T>
+static int upload(p2_circuit* C, T** p, const T* host, size_t count) {
+    if (dalloc(C, p, count)) return P2_ERR_HIP;
+    if (count) HIPCHECK(hipMemcpy(*p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Launch with optional per-kernel event timing on the proving stream.
+#define LAUNCH(C, name, kernel, grid, block, shmem, ...)                                              \
+    do {                                                                                              \
+        hipEvent_t _e0 = nullptr, _e1 = nullptr;                                                      \
+        if ((C)->timing_on) {                                                                         \
+            hipEventCreate(&_e0);                                                                     \
+            hipEventCreate(&_e1);                                                                     \
+            hipEventRecord(_e0, (C)->stream);                                                         \
+        }                                                                                             \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (C)->stream, __VA_ARGS__);                     \
+        if ((C)->timing_on) {                                                                         \
+            hipEventRecord(_e1, (C)->stream);                                                         \
+            (C)->pending.push_back({name, {_e0, _e1}});                                               \
+        }                                                                                             \
+        HIPCHECK(hipGetLastError());                                                                  \
+    } while (0)
+
+static inline dim3 g1(size_t work, u32 block, u32 y = 1, u32 z = 1) { return dim3((u32)((work + block - 1) / block), y, z); }
+
+// ---------------------------------------------------------------------------------- building blocks
+static int run_ntt(p2_circuit* C, const char* name, NttArgs a, u32 cols, u32 batch) {
+    size_t shmem = (size_t)8 << a.logn;
+    a.log_nmax = (int)C->logn;
+    LAUNCH(C, name, k_ntt_lds, dim3(cols * a.cosets, batch), dim3(1024), shmem, a);
+    return 0;
+}
+// values [cols][n] -> coeffs [cols][n]
+static int intt_cols(p2_circuit* C, const u64* vals, u64* coeffs, u32 cols, size_t batch_stride, u32 batch) {
+    NttArgs a{};
+    a.in = vals;
+    a.out = coeffs;
+    a.tw = C->d_tw_inv;
+    a.post_scalar = gl::inv((u64)C->n % gl::P);
+    a.in_col_stride = a.out_col_stride = C->n;
+    a.in_batch_stride = a.out_batch_stride = batch_stride;
+    a.logn = (int)C->logn;
+    a.cosets = 1;
+    a.bitrev_out = 1;
+    return run_ntt(C, "intt", a, cols, batch);
+}
+// coeffs [cols][n_r] -> lde [cols][8 n_r] (bit-reversed order)
+static int lde_cols(p2_circuit* C, const u64* coeffs, size_t in_batch_stride, u64* lde, size_t out_batch_stride, u32 cols, u32 round, u32 batch) {
+    u32 logn_r = C->logn;
+    for (u32 r = 0; r < round; r++) logn_r -= C->arities[r];
+    NttArgs a{};
+    a.in = coeffs;
+    a.out = lde;
+    a.tw = C->d_tw_fwd;
+    a.pre = C->d_shift_pows[round];
+    a.post_scalar = 1;
+    a.in_col_stride = (size_t)1 << logn_r;
+    a.out_col_stride = (size_t)8 << logn_r;
+    a.in_batch_stride = in_batch_stride;
+    a.out_batch_stride = out_batch_stride;
+    a.logn = (int)logn_r;
+    a.cosets = 1 << C->c.cfg.rate_bits;
+    for (u32 j = 0; j < 8; j++) a.block_of_coset[j] = gl::bitrev(j, (int)C->c.cfg.rate_bits);
+    return run_ntt(C, "lde", a, cols, batch);
+}
+static int merkle_build(p2_circuit* C, const u64* data, u32 cols, u32 active, size_t col_stride, size_t batch_stride, Tree& t, u32 batch) {
+    size_t leaves = (size_t)1 << t.bits;
+    LAUNCH(C, "hash_leaves", k_hash_leaves, g1(leaves, 256, batch), dim3(256), 0, data, (int)cols, (int)active, col_stride, batch_stride, leaves, t.dig,
+           t.stride());
+    for (u32 l = 0; l + C->c.cfg.cap_height < t.bits; l++) {
+        size_t parents = leaves >> (l + 1);
+        size_t off_c = 4 * (((size_t)2 << t.bits) - ((size_t)2 << (t.bits - l)));
+        size_t off_p = 4 * (((size_t)2 << t.bits) - ((size_t)2 << (t.bits - l - 1)));
+        LAUNCH(C, "merkle_level", k_merkle_level, g1(parents, 256, batch), dim3(256), 0, t.dig + off_c, t.dig + off_p, parents, t.stride());
+    }
+    return 0;
+}
+static size_t cap_off(const Tree& t, u32 cap_height) {
+    u32 l = t.bits - cap_height;
+    return 4 * (((size_t)2 << t.bits) - ((size_t)2 << (t.bits - l)));
+}
+static int challenger(p2_circuit* C, u32 stage, const u64* observe, size_t stride, u32 len, u32 aux, u64 mod, u32 batch) {
+    ChalArgs a{};
+    a.st = C->d_chal_state;
+    a.chal = C->d_chal;
+    a.observe = observe;
+    a.observe_stride = stride;
+    a.observe_len = len;
+    a.batch = batch;
+    a.stage = stage;
+    a.aux = aux;
+    a.mod = mod;
+    a.digest = C->d_digest;
+    a.status = C->d_status;
+    LAUNCH(C, "challenger", k_challenger, g1(batch, 64), dim3(64), 0, a);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- load / preprocess
+static int circuit_setup(p2_circuit* C) {
+    const Circuit& c = C->c;
+    const size_t n = C->n, N = C->N;
+    const u32 R = c.cfg.num_routed_wires, ncc = c.num_constants_cols(), np = c.num_preprocessed();
+    if (upload(C, &C->d_ops, c.ops.data(), c.ops.size())) return P2_ERR_HIP;
+    if (upload(C, &C->d_level_offsets, c.level_offsets.data(), c.level_offsets.size())) return P2_ERR_HIP;
+    if (upload(C, &C->d_wire_slot, c.wire_slot.data(), c.wire_slot.size())) return P2_ERR_HIP;
+    {
+        std::vector<int32_t> idx(c.luts.size() * 65536, -1);
+        std::vector<u32> pairs, offs(1, 0);
+        for (size_t l = 0; l < c.luts.size(); l++) {
+            for (size_t i = 0; i < c.luts[l].size(); i++) {
+                auto pr = c.luts[l][i];
+                if (idx[l * 65536 + pr.first] < 0) idx[l * 65536 + pr.first] = (int32_t)i;
+                pairs.push_back((u32)pr.first | ((u32)pr.second << 16));
+            }
+            offs.push_back((u32)pairs.size());
+        }
+        C->total_lut_entries = pairs.size();
+        if (upload(C, &C->d_lut_idx, idx.data(), idx.size())) return P2_ERR_HIP;
+        if (upload(C, &C->d_lut_pairs, pairs.data(), pairs.size())) return P2_ERR_HIP;
+        if (upload(C, &C->d_lut_offsets, offs.data(), offs.size())) return P2_ERR_HIP;
+        if (upload(C, &C->d_num_lookups, c.num_lookups.data(), c.num_lookups.size())) return P2_ERR_HIP;
+        if (upload(C, &C->d_lookup_rows, c.lookup_rows.data(), c.lookup_rows.size())) return P2_ERR_HIP;
+    }
+    if (upload(C, &C->d_sigmas, c.sigmas.data(), c.sigmas.size())) return P2_ERR_HIP;
+    if (upload(C, &C->d_k_is, c.k_is.data(), c.k_is.size())) return P2_ERR_HIP;
+    // twiddles, subgroup, coset tables (host-computed once; O(n) field ops)
+    {
+        std::vector<u64> sub(n), twf(std::max<size_t>(n / 2, 1)), twi(std::max<size_t>(n / 2, 1));
+        u64 w = gl::root_of_unity((int)C->logn), wi = gl::inv(w), x = 1, xi = 1;
+        for (size_t i = 0; i < n; i++) {
+            sub[i] = x;
+            if (i < n / 2) {
+                twf[i] = x;
+                twi[i] = xi;
+            }
+            x = gl::mul(x, w);
+            xi = gl::mul(xi, wi);
+        }
+        if (upload(C, &C->d_subgroup, sub.data(), n)) return P2_ERR_HIP;
+        if (upload(C, &C->d_tw_fwd, twf.data(), twf.size())) return P2_ERR_HIP;
+        if (upload(C, &C->d_tw_inv, twi.data(), twi.size())) return P2_ERR_HIP;
+    }
+    {
+        // LDE shift tables for round r: bases s_{r,j} = g^(16^r) * w_{8 n_r}^j
+        u32 logn_r = C->logn;
+        u64 shift = gl::MULT_GEN;
+        for (u32 r = 0; r <= C->arities.size(); r++) {
+            size_t n_r = (size_t)1 << logn_r;
+            std::vector<u64> bases(8);
+            u64 wl = gl::root_of_unity((int)(logn_r + c.cfg.rate_bits));
+            for (u32 j = 0; j < 8; j++) bases[j] = gl::mul(shift, gl::pow(wl, j));
+            u64* d_b;
+            if (upload(C, &d_b, bases.data(), 8)) return P2_ERR_HIP;
+            if (dalloc(C, &C->d_shift_pows[r], 8 * n_r)) return P2_ERR_HIP;
+            hipLaunchKernelGGL(k_pow_table, g1(n_r, 256, 8), dim3(256), 0, C->stream, C->d_shift_pows[r], d_b, (u32)n_r, (u64)1);
+            if (r == 0) {
+                std::vector<u64> ib(8);
+                for (u32 j = 0; j < 8; j++) ib[j] = gl::inv(bases[j]);
+                u64* d_ib;
+                if (upload(C, &d_ib, ib.data(), 8)) return P2_ERR_HIP;
+                if (dalloc(C, &C->d_shift_inv_pows, 8 * n_r)) return P2_ERR_HIP;
+                hipLaunchKernelGGL(k_pow_table, g1(n_r, 256, 8), dim3(256), 0, C->stream, C->d_shift_inv_pows, d_ib, (u32)n_r, gl::inv((u64)n % gl::P));
+            }
+            if (r < C->arities.size()) {
+                shift = gl::pow(shift, (u64)1 << C->arities[r]);
+                logn_r -= C->arities[r];
+            }
+        }
+        HIPCHECK(hipGetLastError());
+    }
+    {
+        // per-point tables on the LDE coset (position p <-> natural index rev(p))
+        std::vector<u64> xs(N), l0(N), zh_inv(8), w8inv(8), qscale(8);
+        u64 wl = gl::root_of_unity((int)C->lde_bits);
+        std::vector<u64> nat(N);
+        u64 x = gl::MULT_GEN;
+        for (size_t i = 0; i < N; i++) {
+            nat[i] = x;
+            x = gl::mul(x, wl);
+        }
+        u64 gn = gl::pow(gl::MULT_GEN, n), w8 = gl::root_of_unity((int)c.cfg.rate_bits);
+        std::vector<u64> zh(8);
+        for (u32 j = 0; j < 8; j++) {
+            zh[j] = gl::sub(gl::mul(gn, gl::pow(w8, j)), 1);
+            zh_inv[j] = gl::inv(zh[j]);
+            w8inv[j] = gl::inv(gl::pow(w8, j));
+            qscale[j] = gl::mul(gl::inv(gl::pow(gn, j)), gl::inv(8));
+        }
+        // batch inversion of n*(x-1)
+        std::vector<u64> den(N), pref(N);
+        u64 acc = 1;
+        for (size_t i = 0; i < N; i++) {
+            den[i] = gl::mul((u64)n % gl::P, gl::sub(nat[i], 1));
+            pref[i] = acc;
+            acc = gl::mul(acc, den[i]);
+        }
+        u64 inv_all = gl::inv(acc);
+        for (size_t i = N; i-- > 0;) {
+            u64 di = gl::mul(inv_all, pref[i]);
+            inv_all = gl::mul(inv_all, den[i]);
+            size_t p = gl::bitrev((u32)i, (int)C->lde_bits);
+            xs[p] = nat[i];
+            l0[p] = gl::mul(zh[i & 7], di);
+        }
+        if (upload(C, &C->d_xs, xs.data(), N)) return P2_ERR_HIP;
+        if (upload(C, &C->d_l0, l0.data(), N)) return P2_ERR_HIP;
+        if (upload(C, &C->d_zh_inv, zh_inv.data(), 8)) return P2_ERR_HIP;
+        if (upload(C, &C->d_w8inv, w8inv.data(), 8)) return P2_ERR_HIP;
+        if (upload(C, &C->d_qscale, qscale.data(), 8)) return P2_ERR_HIP;
+    }
+    // constants | sigmas commitment on the device
+    {
+        u64* d_vals;
+        if (dalloc(C, &d_vals, (size_t)np * n)) return P2_ERR_HIP;
+        HIPCHECK(hipMemcpy(d_vals, c.constants.data(), (size_t)ncc * n * 8, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(d_vals + (size_t)ncc * n, c.sigmas.data(), (size_t)R * n * 8, hipMemcpyHostToDevice));
+        if (dalloc(C, &C->d_pre_coeffs, (size_t)np * n)) return P2_ERR_HIP;
+        if (dalloc(C, &C->d_pre_lde, (size_t)np * N)) return P2_ERR_HIP;
+        C->pre_tree.bits = C->lde_bits;
+        if (dalloc(C, &C->pre_tree.dig, C->pre_tree.stride())) return P2_ERR_HIP;
+        if (intt_cols(C, d_vals, C->d_pre_coeffs, np, 0, 1)) return P2_ERR_HIP;
+        if (lde_cols(C, C->d_pre_coeffs, 0, C->d_pre_lde, 0, np, 0, 1)) return P2_ERR_HIP;
+        if (merkle_build(C, C->d_pre_lde, np, np, N, 0, C->pre_tree, 1)) return P2_ERR_HIP;
+        HIPCHECK(hipStreamSynchronize(C->stream));
+        size_t cap_n = (size_t)1 << c.cfg.cap_height;
+        std::vector<u64> cap(4 * cap_n);
+        HIPCHECK(hipMemcpy(cap.data(), C->pre_tree.dig + cap_off(C->pre_tree, c.cfg.cap_height), cap.size() * 8, hipMemcpyDeviceToHost));
+        // circuit digest = hash_no_pad(cap || hash_pad([]) || degree_bits)   (a dozen host permutations)
+        std::vector<u64> parts(cap);
+        {
+            u64 st[12] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};  // hash_pad of the empty domain separator
+            u64 s2[12] = {0};
+            for (int i = 0; i < 8; i++) s2[i] = st[i];
+            gl::poseidon(s2);
+            for (int i = 0; i < 4; i++) s2[i] = st[8 + i];
+            gl::poseidon(s2);
+            for (int i = 0; i < 4; i++) parts.push_back(s2[i]);
+        }
+        parts.push_back(c.degree_bits);
+        u64 st[12] = {0};
+        for (size_t off = 0; off < parts.size(); off += 8) {
+            for (size_t i = 0; i < std::min<size_t>(8, parts.size() - off); i++) st[i] = parts[off + i];
+            gl::poseidon(st);
+        }
+        C->verifier_data = cap;
+        for (int i = 0; i < 4; i++) C->verifier_data.push_back(st[i]);
+        if (upload(C, &C->d_digest, st, 4)) return P2_ERR_HIP;
+    }
+    return 0;
+}
+
+static int alloc_workspace(p2_circuit* C, size_t chunk, u32 n_inputs) {
+    const Circuit& c = C->c;
+    const size_t n = C->n, N = C->N;
+    const u32 zc = c.num_zs_cols(), qc = c.num_quotient_cols(), NC = c.cfg.num_challenges, act = C->active_wires;
+    if (C->chunk >= chunk && C->ws_inputs >= n_inputs) return 0;
+    if (C->chunk != 0) return set_error("workspace already allocated with a smaller shape; create a new p2_circuit"), P2_ERR_INVALID;
+    C->chunk = chunk;
+    C->ws_inputs = std::max<u32>(n_inputs, 1);
+    int e = 0;
+    e |= dalloc(C, &C->d_input_slots, C->ws_inputs);
+    e |= dalloc(C, &C->d_input_values, chunk * C->ws_inputs);
+    e |= dalloc(C, &C->d_values, chunk * c.num_slots);
+    e |= dalloc(C, &C->d_mult, chunk * std::max<size_t>(C->total_lut_entries, 1));
+    e |= dalloc(C, &C->d_status, chunk);
+    e |= dalloc(C, &C->d_wires, chunk * act * n);
+    e |= dalloc(C, &C->d_wcoef, chunk * act * n);
+    e |= dalloc(C, &C->d_wlde, chunk * act * N);
+    e |= dalloc(C, &C->d_zs, chunk * zc * n);
+    e |= dalloc(C, &C->d_zcoef, chunk * zc * n);
+    e |= dalloc(C, &C->d_zlde, chunk * zc * N);
+    e |= dalloc(C, &C->d_permq, chunk * NC * (c.num_partial_products() + 1) * n);
+    e |= dalloc(C, &C->d_lktmp, chunk * NC * (c.num_sldc_polys() + 1) * n);
+    e |= dalloc(C, &C->d_qvals, chunk * NC * N);
+    e |= dalloc(C, &C->d_qres, chunk * NC * N);
+    e |= dalloc(C, &C->d_qcoef, chunk * qc * n);
+    e |= dalloc(C, &C->d_qlde, chunk * qc * N);
+    for (Tree* t : {&C->wtree, &C->ztree, &C->qtree}) {
+        t->bits = C->lde_bits;
+        e |= dalloc(C, &t->dig, chunk * t->stride());
+    }
+    e |= dalloc(C, &C->d_chal_state, chunk);
+    e |= dalloc(C, &C->d_chal, chunk * CH_WORDS);
+    e |= dalloc(C, &C->d_pows, chunk * 8 * n);
+    e |= dalloc(C, &C->d_ev, chunk * 2 * C->ev_count);
+    e |= dalloc(C, &C->d_obs, chunk * 2 * C->n_obs);
+    e |= dalloc(C, &C->d_comp, chunk * 4 * n);
+    u32 logn_r = C->logn;
+    for (u32 r = 0; r <= C->arities.size(); r++) {
+        size_t n_r = (size_t)1 << logn_r;
+        e |= dalloc(C, &C->d_fri_coef[r], chunk * 2 * n_r);
+        if (r < C->arities.size()) {
+            e |= dalloc(C, &C->d_fri_vals[r], chunk * 2 * 8 * n_r);
+            C->fri_tree[r].bits = logn_r + c.cfg.rate_bits - C->arities[r];
+            e |= dalloc(C, &C->fri_tree[r].dig, chunk * C->fri_tree[r].stride());
+            logn_r -= C->arities[r];
+        }
+    }
+    e |= dalloc(C, &C->d_pow_best, chunk);
+    e |= dalloc(C, &C->d_proofs, chunk * C->pbytes);
+    return e ? P2_ERR_HIP : 0;
+}
+
+// ---------------------------------------------------------------------------------- the pipeline
+// d_targets_slots already uploaded to C->d_input_slots; d_values: [batch][n_inputs] device; proofs/status: device.
+static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, uint8_t* d_proofs, int* d_status_out) {
+    const Circuit& c = C->c;
+    const size_t n = C->n, N = C->N;
+    const u32 R = c.cfg.num_routed_wires, NC = c.cfg.num_challenges, npp = c.num_partial_products(), nlp = c.num_lookup_polys();
+    const u32 zc = c.num_zs_cols(), qc = c.num_quotient_cols(), act = C->active_wires, ncc = c.num_constants_cols(), np = c.num_preprocessed();
+    const u32 cap_h = c.cfg.cap_height, cap_words = 4u << cap_h, nsldc = c.num_sldc_polys();
+    const size_t ws = (size_t)act * n, wls = (size_t)act * N, zs_s = (size_t)zc * n, zl_s = (size_t)zc * N;
+    hipStream_t st = C->stream;
+    // 1. witness
+    HIPCHECK(hipMemsetAsync(C->d_mult, 0, (size_t)B * std::max<size_t>(C->total_lut_entries, 1) * 4, st));
+    {
+        WitnessArgs a{};
+        a.ops = C->d_ops;
+        a.level_offsets = C->d_level_offsets;
+        a.num_levels = (u32)c.level_offsets.size() - 1;
+        a.num_slots = c.num_slots;
+        a.n_inputs = n_inputs;
+        a.input_slots = C->d_input_slots;
+        a.input_values = d_values;
+        a.values = C->d_values;
+        a.lut_idx = C->d_lut_idx;
+        a.lut_pairs = C->d_lut_pairs;
+        a.lut_offsets = C->d_lut_offsets;
+        a.mult = C->d_mult;
+        a.total_lut_entries = C->total_lut_entries;
+        a.status = C->d_status;
+        LAUNCH(C, "witness", k_witness, dim3(B), dim3(1024), 0, a);
+    }
+    LAUNCH(C, "fill_wires", k_fill_wires, g1((size_t)R * n, 256, B), dim3(256), 0, C->d_wire_slot, C->d_values, C->d_wires, (size_t)R * n, c.num_slots, ws,
+           C->d_status);
+    if (!c.luts.empty()) {
+        LutRowsArgs a{};
+        a.lut_pairs = C->d_lut_pairs;
+        a.lut_offsets = C->d_lut_offsets;
+        a.rows = C->d_lookup_rows;
+        a.num_lookups = C->d_num_lookups;
+        a.mult = C->d_mult;
+        a.total_lut_entries = C->total_lut_entries;
+        a.wires = C->d_wires;
+        a.wires_batch_stride = ws;
+        a.n = (u32)n;
+        a.num_luts = (u32)c.luts.size();
+        LAUNCH(C, "lut_rows", k_lut_rows, g1(std::max<size_t>(C->total_lut_entries, 256), 256, B), dim3(256), 0, a);
+    }
+    // 2. wires commitment
+    if (intt_cols(C, C->d_wires, C->d_wcoef, act, ws, B)) return P2_ERR_HIP;
+    if (lde_cols(C, C->d_wcoef, ws, C->d_wlde, wls, act, 0, B)) return P2_ERR_HIP;
+    if (merkle_build(C, C->d_wlde, c.cfg.num_wires, act, N, wls, C->wtree, B)) return P2_ERR_HIP;
+    // 3. betas, gammas, deltas
+    if (challenger(C, 0, C->wtree.dig + cap_off(C->wtree, cap_h), C->wtree.stride(), cap_words, nlp ? 1 : 0, 0, B)) return P2_ERR_HIP;
+    // 4. partial products and Z
+    HIPCHECK(hipMemsetAsync(C->d_zs, 0, (size_t)B * zs_s * 8, st));
+    LAUNCH(C, "perm_chunks", k_perm_chunks, g1(n, 256, B, NC * (npp + 1)), dim3(256), 0, C->d_wires, ws, C->d_sigmas, C->d_k_is, C->d_subgroup, C->d_chal,
+           C->d_permq, (size_t)NC * (npp + 1) * n, (u32)n, R, c.cfg.quotient_degree_factor, npp + 1);
+    LAUNCH(C, "perm_scan", k_perm_scan, dim3(NC, B), dim3(1024), 0, C->d_permq, (size_t)NC * (npp + 1) * n, C->d_zs, zs_s, (u32)n, npp + 1, NC);
+    // 5. lookup polynomials
+    if (nlp) {
+        LookupArgs a{};
+        a.wires = C->d_wires;
+        a.wires_batch_stride = ws;
+        a.chal = C->d_chal;
+        a.zs = C->d_zs;
+        a.zs_batch_stride = zs_s;
+        a.tmp = C->d_lktmp;
+        a.tmp_batch_stride = (size_t)NC * (nsldc + 1) * n;
+        a.rows = C->d_lookup_rows;
+        a.n = (u32)n;
+        a.num_luts = (u32)c.luts.size();
+        a.num_sldc = nsldc;
+        a.lut_deg = c.lut_degree();
+        a.lu_deg = c.cfg.quotient_degree_factor - 1;
+        a.num_challenges = NC;
+        a.zs_lookup_col0 = c.num_zs_pp();
+        LAUNCH(C, "lookup_terms", k_lookup_terms, g1(n, 256, B, NC * (nsldc + 1)), dim3(256), 0, a);
+        LAUNCH(C, "lookup_scan", k_lookup_scan, dim3((u32)c.luts.size(), B, NC), dim3(1024), 0, a);
+    }
+    // 6. zs commitment, alphas
+    if (intt_cols(C, C->d_zs, C->d_zcoef, zc, zs_s, B)) return P2_ERR_HIP;
+    if (lde_cols(C, C->d_zcoef, zs_s, C->d_zlde, zl_s, zc, 0, B)) return P2_ERR_HIP;
+    if (merkle_build(C, C->d_zlde, zc, zc, N, zl_s, C->ztree, B)) return P2_ERR_HIP;
+    if (challenger(C, 1, C->ztree.dig + cap_off(C->ztree, cap_h), C->ztree.stride(), cap_words, 0, 0, B)) return P2_ERR_HIP;
+    // 7. quotient
+    {
+        QuotientArgs a{};
+        a.pre_lde = C->d_pre_lde;
+        a.wires_lde = C->d_wlde;
+        a.zs_lde = C->d_zlde;
+        a.wires_batch_stride = wls;
+        a.zs_batch_stride = zl_s;
+        a.chal = C->d_chal;
+        a.xs = C->d_xs;
+        a.l0 = C->d_l0;
+        a.zh_inv = C->d_zh_inv;
+        a.k_is = C->d_k_is;
+        a.out = C->d_qvals;
+        a.out_batch_stride = (size_t)NC * N;
+        a.n = (u32)n;
+        a.logn = C->logn;
+        a.rate_bits = c.cfg.rate_bits;
+        a.R = R;
+        a.ncc = ncc;
+        a.nsel = c.num_selectors();
+        a.nls = c.num_lookup_selectors;
+        a.NC = NC;
+        a.npp = npp;
+        a.qdf = c.cfg.quotient_degree_factor;
+        a.num_luts = (u32)c.luts.size();
+        a.nsldc = nsldc;
+        a.lut_deg = nlp ? c.lut_degree() : 0;
+        a.nlp = nlp;
+        a.num_gates = (u32)c.gates.size();
+        a.num_gate_constraints = c.num_gate_constraints;
+        for (u32 g = 0; g < c.gates.size(); g++) {
+            a.gate_kind[g] = c.gates[g];
+            a.gate_sel[g] = c.selector_index[g];
+            a.group_lo[g] = c.groups[c.selector_index[g]].first;
+            a.group_hi[g] = c.groups[c.selector_index[g]].second;
+        }
+        for (u32 l = 0; l < c.luts.size(); l++) a.lut_last_row[l] = c.lookup_rows[l].last_lut;
+        a.zs_values = C->d_zs;
+        a.zs_values_batch_stride = zs_s;
+        LAUNCH(C, "quotient", k_quotient, g1(N, 256, B), dim3(256), 0, a);
+        // coset-wise inverse transform: residues r_j, then the 8-point cross-coset DFT
+        NttArgs t{};
+        t.in = C->d_qvals;
+        t.out = C->d_qres;
+        t.tw = C->d_tw_inv;
+        t.post = C->d_shift_inv_pows;
+        t.post_scalar = 1;
+        t.in_col_stride = t.out_col_stride = N;
+        t.in_batch_stride = t.out_batch_stride = (size_t)NC * N;
+        t.logn = (int)C->logn;
+        t.cosets = 8;
+        t.bitrev_in = 1;
+        t.bitrev_out = 1;
+        t.in_coset_blocks = 1;
+        // input block rev3(j) holds coset j; residue r_j is written to block j
+        for (u32 j = 0; j < 8; j++) t.block_of_coset[j] = gl::bitrev(j, 3);
+        // (output uses the same block index; k_quotient_chunks reads block rev3(j) as coset j)
+        if (run_ntt(C, "quotient_intt", t, NC, B)) return P2_ERR_HIP;
+        LAUNCH(C, "quotient_chunks", k_quotient_chunks_rev, g1(n, 256, B, NC), dim3(256), 0, C->d_qres, C->d_qcoef, (u32)n, (size_t)NC * N, (size_t)qc * n,
+               C->d_w8inv, C->d_qscale);
+    }
+    if (lde_cols(C, C->d_qcoef, (size_t)qc * n, C->d_qlde, (size_t)qc * N, qc, 0, B)) return P2_ERR_HIP;
+    if (merkle_build(C, C->d_qlde, qc, qc, N, (size_t)qc * N, C->qtree, B)) return P2_ERR_HIP;
+    if (challenger(C, 2, C->qtree.dig + cap_off(C->qtree, cap_h), C->qtree.stride(), cap_words, c.degree_bits, 0, B)) return P2_ERR_HIP;
+    // 8. openings
+    LAUNCH(C, "zeta_pows", k_zeta_pows, g1(n, 256, B, 4), dim3(256), 0, C->d_chal, C->d_pows, (size_t)8 * n, (u32)n, gl::root_of_unity((int)C->logn));
+    HIPCHECK(hipMemsetAsync(C->d_ev, 0, (size_t)B * 2 * C->ev_count * 8, st));
+    {
+        const size_t evs = 2 * (size_t)C->ev_count;
+        u64* ev = C->d_ev;
+        LAUNCH(C, "eval_polys", k_eval_polys, dim3(np, B), dim3(256), 0, C->d_pre_coeffs, (size_t)0, C->d_pows, (size_t)8 * n, (u32)n, ev, evs);
+        LAUNCH(C, "eval_polys", k_eval_polys, dim3(act, B), dim3(256), 0, C->d_wcoef, ws, C->d_pows, (size_t)8 * n, (u32)n, ev + 2 * (size_t)np, evs);
+        LAUNCH(C, "eval_polys", k_eval_polys, dim3(zc, B), dim3(256), 0, C->d_zcoef, zs_s, C->d_pows, (size_t)8 * n, (u32)n, ev + 2 * (size_t)(np + c.cfg.num_wires), evs);
+        LAUNCH(C, "eval_polys", k_eval_polys, dim3(zc, B), dim3(256), 0, C->d_zcoef, zs_s, C->d_pows + 2 * n, (size_t)8 * n, (u32)n,
+               ev + 2 * (size_t)(np + c.cfg.num_wires + zc), evs);
+        LAUNCH(C, "eval_polys", k_eval_polys, dim3(qc, B), dim3(256), 0, C->d_qcoef, (size_t)qc * n, C->d_pows, (size_t)8 * n, (u32)n,
+               ev + 2 * (size_t)(np + c.cfg.num_wires + 2 * zc), evs);
+        LAUNCH(C, "gather_ext", k_gather_ext, g1(C->n_obs, 256, B), dim3(256), 0, C->d_ev, evs, C->d_map_obs, C->n_obs, C->d_obs, (size_t)2 * C->n_obs);
+    }
+    if (challenger(C, 3, C->d_obs, (size_t)2 * C->n_obs, 2 * C->n_obs, 0, 0, B)) return P2_ERR_HIP;
+    // 9. FRI: compose, divide, commit phase
+    LAUNCH(C, "fri_compose", k_fri_compose, g1(n, 256, B), dim3(256), 0, C->d_polyrefs, C->n_b0, C->n_b1, C->d_chal, (u32)n, C->d_comp, (size_t)4 * n);
+    LAUNCH(C, "fri_divide", k_fri_divide, dim3(B), dim3(1024), 0, C->d_comp, (size_t)4 * n, C->d_pows, (size_t)8 * n, C->d_chal, (u32)n, C->n_b1, C->d_fri_coef[0],
+           (size_t)2 * n);
+    {
+        u32 logn_r = C->logn;
+        for (u32 r = 0; r < C->arities.size(); r++) {
+            size_t n_r = (size_t)1 << logn_r, len = 8 * n_r;
+            u32 arity = 1u << C->arities[r];
+            if (lde_cols(C, C->d_fri_coef[r], 2 * n_r, C->d_fri_vals[r], 2 * len, 2, r, B)) return P2_ERR_HIP;
+            Tree& t = C->fri_tree[r];
+            size_t leaves = len / arity;
+            LAUNCH(C, "hash_fri_leaves", k_hash_fri_leaves, g1(leaves, 256, B), dim3(256), 0, C->d_fri_vals[r], len, 2 * len, (int)arity, t.dig, t.stride());
+            for (u32 l = 0; l + cap_h < t.bits; l++) {
+                size_t parents = leaves >> (l + 1);
+                size_t off_c = 4 * (((size_t)2 << t.bits) - ((size_t)2 << (t.bits - l)));
+                size_t off_p = 4 * (((size_t)2 << t.bits) - ((size_t)2 << (t.bits - l - 1)));
+                LAUNCH(C, "merkle_level", k_merkle_level, g1(parents, 256, B), dim3(256), 0, t.dig + off_c, t.dig + off_p, parents, t.stride());
+            }
+            if (challenger(C, 4, t.dig + cap_off(t, cap_h), t.stride(), cap_words, r, 0, B)) return P2_ERR_HIP;
+            size_t n_next = n_r >> C->arities[r];
+            LAUNCH(C, "fri_fold", k_fri_fold, g1(n_next, 256, B), dim3(256), 0, C->d_fri_coef[r], n_r, 2 * n_r, C->d_fri_coef[r + 1], n_next, 2 * n_next, C->d_chal, r,
+                   arity);
+            logn_r -= C->arities[r];
+        }
+        // final polynomial (interleave components for observation)
+        size_t fl = (size_t)1 << logn_r;
+        u32 R_ = (u32)C->arities.size();
+        LAUNCH(C, "interleave", k_interleave_ext, g1(fl, 256, B), dim3(256), 0, C->d_fri_coef[R_], fl, 2 * fl, C->d_obs, (size_t)2 * C->n_obs);
+        if (challenger(C, 5, C->d_obs, (size_t)2 * C->n_obs, (u32)(2 * fl), 0, 0, B)) return P2_ERR_HIP;
+        // proof of work
+        HIPCHECK(hipMemsetAsync(C->d_pow_best, 0xFF, (size_t)B * 8, st));
+        LAUNCH(C, "pow", k_pow, dim3(1u << 14, B), dim3(256), 0, C->d_chal_state, C->d_chal, (int)c.cfg.pow_bits, C->d_pow_best);
+        LAUNCH(C, "pow_finish", k_pow_finish, g1(B, 64), dim3(64), 0, C->d_chal, C->d_pow_best, B, C->d_status);
+        if (challenger(C, 6, C->d_obs, 0, 0, c.cfg.num_query_rounds, (u64)N, B)) return P2_ERR_HIP;
+        // 10. proof assembly
+        size_t off = 0;
+        const size_t pb = C->pbytes;
+        for (Tree* t : {&C->wtree, &C->ztree, &C->qtree}) {
+            LAUNCH(C, "proof_copy", k_proof_copy, g1(cap_words, 64, B), dim3(64), 0, t->dig + cap_off(*t, cap_h), t->stride(), cap_words, d_proofs, pb, off);
+            off += 8 * (size_t)cap_words;
+        }
+        LAUNCH(C, "proof_gather", k_proof_gather_ext, g1(C->n_ser, 256, B), dim3(256), 0, C->d_ev, 2 * (size_t)C->ev_count, C->d_map_ser, C->n_ser, d_proofs, pb, off);
+        off += 16 * (size_t)C->n_ser;
+        for (u32 r = 0; r < R_; r++) {
+            Tree& t = C->fri_tree[r];
+            LAUNCH(C, "proof_copy", k_proof_copy, g1(cap_words, 64, B), dim3(64), 0, t.dig + cap_off(t, cap_h), t.stride(), cap_words, d_proofs, pb, off);
+            off += 8 * (size_t)cap_words;
+        }
+        QueryArgs q{};
+        const u64* ldes[4] = {C->d_pre_lde, C->d_wlde, C->d_zlde, C->d_qlde};
+        const size_t lstr[4] = {0, wls, zl_s, (size_t)qc * N};
+        const Tree* trees[4] = {&C->pre_tree, &C->wtree, &C->ztree, &C->qtree};
+        const u32 colsv[4] = {np, c.cfg.num_wires, zc, qc};
+        const u32 actv[4] = {np, act, zc, qc};
+        size_t qbytes = 0;
+        for (int o = 0; o < 4; o++) {
+            q.oracles[o].lde = ldes[o];
+            q.oracles[o].lde_batch_stride = lstr[o];
+            q.oracles[o].digests = trees[o]->dig;
+            q.oracles[o].dig_batch_stride = o == 0 ? 0 : trees[o]->stride();
+            q.oracles[o].cols = colsv[o];
+            q.oracles[o].active_cols = actv[o];
+            qbytes += 8 * (size_t)colsv[o] + 1 + 32 * (size_t)(C->lde_bits - cap_h);
+        }
+        q.lde_bits = C->lde_bits;
+        q.cap_height = cap_h;
+        q.num_queries = c.cfg.num_query_rounds;
+        q.num_rounds = R_;
+        u32 lb = C->lde_bits;
+        for (u32 r = 0; r < R_; r++) {
+            q.arity_bits[r] = C->arities[r];
+            q.fri_vals[r] = C->d_fri_vals[r];
+            q.fri_vals_batch_stride[r] = (size_t)2 << lb;
+            q.fri_bits[r] = lb;
+            q.fri_digests[r] = C->fri_tree[r].dig;
+            q.fri_dig_batch_stride[r] = C->fri_tree[r].stride();
+            qbytes += 16 * ((size_t)1 << C->arities[r]) + 1 + 32 * (size_t)(lb - C->arities[r] - cap_h);
+            lb -= C->arities[r];
+        }
+        q.chal = C->d_chal;
+        q.proofs = d_proofs;
+        q.proof_bytes = pb;
+        q.queries_off = off;
+        q.query_bytes = qbytes;
+        LAUNCH(C, "write_queries", k_write_queries, dim3(c.cfg.num_query_rounds, B), dim3(256), 0, q);
+        off += qbytes * c.cfg.num_query_rounds;
+        LAUNCH(C, "proof_copy_ext", k_proof_copy_ext, g1(fl, 64, B), dim3(64), 0, C->d_fri_coef[R_], 2 * fl, fl, (u32)fl, d_proofs, pb, off);
+        off += 16 * fl;
+        LAUNCH(C, "proof_copy", k_proof_copy, g1(1, 64, B), dim3(64), 0, C->d_chal + CH_POW, (size_t)CH_WORDS, 1u, d_proofs, pb, off);
+        off += 8;
+        if (off != pb) return set_error("internal: proof layout size mismatch"), P2_ERR_INVALID;
+    }
+    LAUNCH(C, "finish", k_finish, g1(C->pbytes, 256, B), dim3(256), 0, C->d_status, d_status_out, d_proofs, C->pbytes, B);
+    return 0;
+}
+
+static void collect_timing(p2_circuit* C) {
+    for (auto& pe : C->pending) {
+        float ms = 0;
+        hipEventSynchronize(pe.second.second);
+        hipEventElapsedTime(&ms, pe.second.first, pe.second.second);
+        auto& t = C->times[pe.first];
+        t.first += ms;
+        t.second++;
+        hipEventDestroy(pe.second.first);
+        hipEventDestroy(pe.second.second);
+    }
+    C->pending.clear();
+}
+
+extern "C" {
+
+int p2_gpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
+    p2_circuit* C = nullptr;
+    try {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+            set_error("no HIP device available: the prover has no CPU fallback");
+            return nullptr;
+        }
+        if (device < 0 || device >= ndev) {
+            set_error("device index out of range");
+            return nullptr;
+        }
+        C = new p2_circuit();
+        C->c = deserialize(blob, len);
+        const Circuit& c = C->c;
+        if (c.cfg.rate_bits != 3 || c.cfg.num_challenges != 2 || c.cfg.quotient_degree_factor != 8 || c.cfg.num_routed_wires != 80 || c.cfg.arity_bits != 4 ||
+            c.cfg.num_query_rounds > 64 || c.gates.size() > 8 || c.luts.size() > 4)
+            throw std::runtime_error("only CircuitConfig::standard_recursion_config() is supported");
+        if (c.degree_bits > 14) throw std::runtime_error("degree_bits > 14 needs the multi-pass NTT (not built yet)");
+        C->device = device;
+        C->logn = c.degree_bits;
+        C->n = c.n();
+        C->lde_bits = c.degree_bits + c.cfg.rate_bits;
+        C->N = C->n << c.cfg.rate_bits;
+        C->arities = c.reduction_arity_bits();
+        C->active_wires = c.cfg.num_routed_wires;  // the gates of these circuits use routed wires only; the rest are 0
+        C->pbytes = proof_bytes(c);
+        if (hipSetDevice(device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+        if (hipStreamCreate(&C->stream) != hipSuccess) throw std::runtime_error("hipStreamCreate failed");
+        if (hipFuncSetAttribute((const void*)k_ntt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            throw std::runtime_error("cannot raise the dynamic LDS limit to 128 KiB");
+        // opening maps
+        const u32 np = c.num_preprocessed(), W = c.cfg.num_wires, zc = c.num_zs_cols(), qc = c.num_quotient_cols(), NC = c.cfg.num_challenges;
+        const u32 ncc = c.num_constants_cols(), nzpp = c.num_zs_pp();
+        const u32 E_PRE = 0, E_W = np, E_Z = np + W, E_ZN = E_Z + zc, E_Q = E_ZN + zc;
+        C->ev_count = E_Q + qc;
+        std::vector<u32> obs, ser;
+        auto range = [](std::vector<u32>& v, u32 base, u32 a, u32 b) {
+            for (u32 i = a; i < b; i++) v.push_back(base + i);
+        };
+        range(obs, E_PRE, 0, np);
+        range(obs, E_W, 0, W);
+        range(obs, E_Z, 0, nzpp);
+        range(obs, E_Q, 0, qc);
+        range(obs, E_Z, nzpp, zc);
+        range(obs, E_ZN, 0, NC);
+        range(obs, E_ZN, nzpp, zc);
+        range(ser, E_PRE, 0, ncc);
+        range(ser, E_PRE, ncc, np);
+        range(ser, E_W, 0, W);
+        range(ser, E_Z, 0, NC);
+        range(ser, E_ZN, 0, NC);
+        range(ser, E_Z, NC, nzpp);
+        range(ser, E_Q, 0, qc);
+        range(ser, E_Z, nzpp, zc);
+        range(ser, E_ZN, nzpp, zc);
+        C->n_obs = (u32)obs.size();
+        C->n_ser = (u32)ser.size();
+        size_t fl = C->n;
+        for (u32 a : C->arities) fl >>= a;
+        if (fl > C->n_obs) throw std::runtime_error("final polynomial larger than the observation buffer");
+        if (upload(C, &C->d_map_obs, obs.data(), obs.size()) || upload(C, &C->d_map_ser, ser.data(), ser.size())) throw std::runtime_error(g_last_error);
+        if (circuit_setup(C)) throw std::runtime_error(g_last_error);
+        return C;
+    } catch (std::exception& e) {
+        set_error(e.what());
+        if (C) p2_circuit_free(C);
+        return nullptr;
+    }
+}
+
+void p2_circuit_free(p2_circuit* C) {
+    if (!C) return;
+    hipSetDevice(C->device);
+    if (C->stream) hipStreamSynchronize(C->stream);
+    for (void* p : C->allocs) hipFree(p);
+    if (C->stream) hipStreamDestroy(C->stream);
+    delete C;
+}
+
+int p2_circuit_verifier_data(const p2_circuit* C, uint64_t* out, size_t cap, size_t* n_written) {
+    if (cap < C->verifier_data.size()) return set_error("buffer too small"), P2_ERR_INVALID;
+    memcpy(out, C->verifier_data.data(), C->verifier_data.size() * 8);
+    *n_written = C->verifier_data.size();
+    return P2_OK;
+}
+size_t p2_circuit_proof_bytes(const p2_circuit* C) { return C->pbytes; }
+
+static int setup_polyrefs(p2_circuit* C) {
+    if (C->d_polyrefs) return 0;
+    const Circuit& c = C->c;
+    const u32 np = c.num_preprocessed(), W = c.cfg.num_wires, zc = c.num_zs_cols(), qc = c.num_quotient_cols(), NC = c.cfg.num_challenges, nzpp = c.num_zs_pp();
+    const size_t n = C->n;
+    std::vector<PolyRef> v;
+    for (u32 i = 0; i < np; i++) v.push_back({C->d_pre_coeffs, 0, i, 0});
+    for (u32 i = 0; i < W; i++) v.push_back({i < C->active_wires ? C->d_wcoef : nullptr, (size_t)C->active_wires * n, i, 0});
+    for (u32 i = 0; i < nzpp; i++) v.push_back({C->d_zcoef, (size_t)zc * n, i, 0});
+    for (u32 i = 0; i < qc; i++) v.push_back({C->d_qcoef, (size_t)qc * n, i, 0});
+    for (u32 i = nzpp; i < zc; i++) v.push_back({C->d_zcoef, (size_t)zc * n, i, 0});
+    C->n_b0 = (u32)v.size();
+    for (u32 i = 0; i < NC; i++) v.push_back({C->d_zcoef, (size_t)zc * n, i, 0});
+    for (u32 i = nzpp; i < zc; i++) v.push_back({C->d_zcoef, (size_t)zc * n, i, 0});
+    C->n_b1 = (u32)v.size() - C->n_b0;
+    return upload(C, &C->d_polyrefs, v.data(), v.size());
+}
+
+int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets, size_t n_targets, const uint64_t* d_values, uint8_t* d_proofs, int* d_status,
+                          void* stream) {
+    std::lock_guard<std::mutex> lock(C->mu);
+    (void)stream;
+    HIPCHECK(hipSetDevice(C->device));
+    std::vector<u32> slots(n_targets);
+    for (size_t i = 0; i < n_targets; i++) {
+        if (targets[i] >= C->c.vt_slot.size() || C->c.vt_slot[targets[i]] < 0) return set_error("input target is not a virtual target of this circuit"), P2_ERR_INVALID;
+        slots[i] = (u32)C->c.vt_slot[targets[i]];
+    }
+    size_t chunk = C->chunk ? C->chunk : std::min<size_t>(std::max<size_t>(batch, 1), 32);
+    if (alloc_workspace(C, chunk, (u32)n_targets)) return P2_ERR_HIP;
+    if (setup_polyrefs(C)) return P2_ERR_HIP;
+    HIPCHECK(hipMemcpyAsync(C->d_input_slots, slots.data(), n_targets * 4, hipMemcpyHostToDevice, C->stream));
+    HIPCHECK(hipStreamSynchronize(C->stream));  // `slots` is a stack-lifetime host buffer
+    for (size_t done = 0; done < batch; done += C->chunk) {
+        u32 B = (u32)std::min(C->chunk, batch - done);
+        int rc = prove_chunk(C, B, (u32)n_targets, d_values + done * n_targets, d_proofs + done * C->pbytes, d_status + done);
+        if (rc) return rc;
+    }
+    return P2_OK;
+}
+
+int p2_circuit_synchronize(p2_circuit* C) {
+    HIPCHECK(hipSetDevice(C->device));
+    HIPCHECK(hipStreamSynchronize(C->stream));
+    if (C->timing_on) collect_timing(C);
+    return P2_OK;
+}
+
+int p2_prove_batch(p2_circuit* C, size_t batch, const p2_assignment* inputs, uint8_t* proofs, int* status) {
+    if (batch == 0) return P2_OK;
+    HIPCHECK(hipSetDevice(C->device));
+    // Every PartialWitness of the batch must assign the same target list (same order); duplicates are allowed.
+    size_t nt = inputs[0].count;
+    for (size_t i = 1; i < batch; i++) {
+        if (inputs[i].count != nt || memcmp(inputs[i].targets, inputs[0].targets, nt * 8) != 0)
+            return set_error("all witnesses of a batch must assign the same targets in the same order"), P2_ERR_INVALID;
+    }
+    std::vector<u64> hv(batch * std::max<size_t>(nt, 1));
+    for (size_t i = 0; i < batch; i++)
+        for (size_t k = 0; k < nt; k++) hv[i * nt + k] = inputs[i].values[k];
+    u64* d_vals = nullptr;
+    uint8_t* d_proofs = nullptr;
+    int* d_stat = nullptr;
+    HIPCHECK(hipMalloc((void**)&d_vals, hv.size() * 8));
+    HIPCHECK(hipMalloc((void**)&d_proofs, batch * C->pbytes));
+    HIPCHECK(hipMalloc((void**)&d_stat, batch * sizeof(int)));
+    HIPCHECK(hipMemcpy(d_vals, hv.data(), hv.size() * 8, hipMemcpyHostToDevice));
+    int rc = p2_prove_batch_device(C, batch, inputs[0].targets, nt, d_vals, d_proofs, d_stat, nullptr);
+    if (rc == P2_OK) rc = p2_circuit_synchronize(C);
+    if (rc == P2_OK) {
+        if (hipMemcpy(proofs, d_proofs, batch * C->pbytes, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(status, d_stat, batch * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+            set_error("copying proofs back failed");
+            rc = P2_ERR_HIP;
+        }
+    }
+    hipFree(d_vals);
+    hipFree(d_proofs);
+    hipFree(d_stat);
+    return rc;
+}
+
+int p2_circuit_set_timing(p2_circuit* C, int enable) {
+    C->timing_on = enable != 0;
+    C->times.clear();
+    return P2_OK;
+}
+size_t p2_circuit_get_timing(p2_circuit* C, p2_kernel_time* out, size_t cap) {
+    size_t k = 0;
+    for (auto& kv : C->times) {
+        if (k < cap) {
+            memset(&out[k], 0, sizeof(out[k]));
+            strncpy(out[k].name, kv.first.c_str(), sizeof(out[k].name) - 1);
+            out[k].ms = kv.second.first;
+            out[k].count = kv.second.second;
+        }
+        k++;
+    }
+    return k;
+}
+
+int p2_circuit_debug_read(p2_circuit* C, const char* name_c, size_t index, uint64_t* out, size_t cap, size_t* n_written) {
+    HIPCHECK(hipSetDevice(C->device));
+    HIPCHECK(hipStreamSynchronize(C->stream));
+    const Circuit& c = C->c;
+    std::string name(name_c);
+    const size_t n = C->n, N = C->N;
+    const u32 zc = c.num_zs_cols(), qc = c.num_quotient_cols(), act = C->active_wires, cap_words = 4u << c.cfg.cap_height;
+    const u64* src = nullptr;
+    size_t count = 0;
+    if (name == "pre_cap") { src = C->pre_tree.dig + cap_off(C->pre_tree, c.cfg.cap_height); count = cap_words; }
+    else if (name == "pre_coeffs") { src = C->d_pre_coeffs; count = (size_t)c.num_preprocessed() * n; }
+    else if (index >= C->chunk) return set_error("index beyond the last chunk"), P2_ERR_INVALID;
+    else if (name == "values") { src = C->d_values + index * c.num_slots; count = c.num_slots; }
+    else if (name == "wires") { src = C->d_wires + index * act * n; count = (size_t)act * n; }
+    else if (name == "wires_coeffs") { src = C->d_wcoef + index * act * n; count = (size_t)act * n; }
+    else if (name == "wires_lde") { src = C->d_wlde + index * act * N; count = (size_t)act * N; }
+    else if (name == "wires_cap") { src = C->wtree.dig + index * C->wtree.stride() + cap_off(C->wtree, c.cfg.cap_height); count = cap_words; }
+    else if (name == "zs") { src = C->d_zs + index * zc * n; count = (size_t)zc * n; }
+    else if (name == "zs_cap") { src = C->ztree.dig + index * C->ztree.stride() + cap_off(C->ztree, c.cfg.cap_height); count = cap_words; }
+    else if (name == "quotient_values") { src = C->d_qvals + index * 2 * N; count = 2 * N; }
+    else if (name == "quotient_coeffs") { src = C->d_qcoef + index * qc * n; count = (size_t)qc * n; }
+    else if (name == "quotient_cap") { src = C->qtree.dig + index * C->qtree.stride() + cap_off(C->qtree, c.cfg.cap_height); count = cap_words; }
+    else if (name == "challenges") { src = C->d_chal + index * CH_WORDS; count = CH_WORDS; }
+    else if (name == "openings") { src = C->d_ev + index * 2 * C->ev_count; count = 2 * (size_t)C->ev_count; }
+    else if (name == "fri_final_poly_in") { src = C->d_fri_coef[0] + index * 2 * n; count = 2 * n; }
+    else return set_error("unknown debug buffer"), P2_ERR_INVALID;
+    if (count > cap) return set_error("debug buffer too small"), P2_ERR_INVALID;
+    HIPCHECK(hipMemcpy(out, src, count * 8, hipMemcpyDeviceToHost));
+    *n_written = count;
+    return P2_OK;
+}
+
+// ---------------------------------------------------------------------------------- primitives (parity tests)
+static int pick_device(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_error("no HIP device available"), P2_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return set_error("device index out of range"), P2_ERR_INVALID;
+    HIPCHECK(hipSetDevice(device));
+    return 0;
+}
+int p2_gpu_poseidon(uint64_t* states, size_t n_perm, int device) {
+    if (int rc = pick_device(device)) return rc;
+    u64* d;
+    HIPCHECK(hipMalloc((void**)&d, n_perm * 96));
+    HIPCHECK(hipMemcpy(d, states, n_perm * 96, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_poseidon_states, g1(n_perm, 256), dim3(256), 0, 0, d, n_perm);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpy(states, d, n_perm * 96, hipMemcpyDeviceToHost));
+    hipFree(d);
+    return P2_OK;
+}
+// A throw-away circuit-less context for the NTT / Merkle primitives
+struct PrimCtx {
+    p2_circuit C;
+    int init(int device, int degree_bits) {
+        if (int rc = pick_device(device)) return rc;
+        C.device = device;
+        C.logn = (u32)degree_bits;
+        C.n = (size_t)1 << degree_bits;
+        C.c.degree_bits = (u32)degree_bits;
+        C.lde_bits = C.logn + 3;
+        C.N = C.n << 3;
+        HIPCHECK(hipStreamCreate(&C.stream));
+        HIPCHECK(hipFuncSetAttribute((const void*)k_ntt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        size_t n = C.n;
+        std::vector<u64> twf(std::max<size_t>(n / 2, 1)), twi(std::max<size_t>(n / 2, 1));
+        u64 w = gl::root_of_unity(degree_bits), wi = gl::inv(w), x = 1, xi = 1;
+        for (size_t i = 0; i < n / 2; i++) {
+            twf[i] = x;
+            twi[i] = xi;
+            x = gl::mul(x, w);
+            xi = gl::mul(xi, wi);
+        }
+        if (upload(&C, &C.d_tw_fwd, twf.data(), twf.size()) || upload(&C, &C.d_tw_inv, twi.data(), twi.size())) return P2_ERR_HIP;
+        std::vector<u64> bases(8);
+        u64 wl = gl::root_of_unity(degree_bits + 3);
+        for (u32 j = 0; j < 8; j++) bases[j] = gl::mul(gl::MULT_GEN, gl::pow(wl, j));
+        u64* d_b;
+        if (upload(&C, &d_b, bases.data(), 8)) return P2_ERR_HIP;
+        if (dalloc(&C, &C.d_shift_pows[0], 8 * n)) return P2_ERR_HIP;
+        hipLaunchKernelGGL(k_pow_table, g1(n, 256, 8), dim3(256), 0, C.stream, C.d_shift_pows[0], d_b, (u32)n, (u64)1);
+        HIPCHECK(hipGetLastError());
+        return 0;
+    }
+    ~PrimCtx() {
+        if (C.stream) hipStreamSynchronize(C.stream);
+        for (void* p : C.allocs) hipFree(p);
+        if (C.stream) hipStreamDestroy(C.stream);
+    }
+};
+int p2_gpu_intt(const uint64_t* values, size_t cols, int degree_bits, uint64_t* coeffs, int device) {
+    if (degree_bits < 1 || degree_bits > 14) return set_error("degree_bits must be in 1..14"), P2_ERR_INVALID;
+    PrimCtx ctx;
+    if (int rc = ctx.init(device, degree_bits)) return rc;
+    p2_circuit* C = &ctx.C;
+    size_t n = C->n;
+    u64 *d_in, *d_out;
+    if (upload(C, &d_in, values, cols * n) || dalloc(C, &d_out, cols * n)) return P2_ERR_HIP;
+    if (intt_cols(C, d_in, d_out, (u32)cols, 0, 1)) return P2_ERR_HIP;
+    HIPCHECK(hipStreamSynchronize(C->stream));
+    HIPCHECK(hipMemcpy(coeffs, d_out, cols * n * 8, hipMemcpyDeviceToHost));
+    return P2_OK;
+}
+int p2_gpu_lde(const uint64_t* coeffs, size_t cols, int degree_bits, int rate_bits, uint64_t* lde, int device) {
+    if (degree_bits < 1 || degree_bits > 14 || rate_bits != 3) return set_error("degree_bits must be in 1..14 and rate_bits 3"), P2_ERR_INVALID;
+    PrimCtx ctx;
+    if (int rc = ctx.init(device, degree_bits)) return rc;
+    p2_circuit* C = &ctx.C;
+    C->c.cfg.rate_bits = 3;
+    size_t n = C->n;
+    u64 *d_in, *d_out;
+    if (upload(C, &d_in, coeffs, cols * n) || dalloc(C, &d_out, cols * 8 * n)) return P2_ERR_HIP;
+    if (lde_cols(C, d_in, 0, d_out, 0, (u32)cols, 0, 1)) return P2_ERR_HIP;
+    HIPCHECK(hipStreamSynchronize(C->stream));
+    HIPCHECK(hipMemcpy(lde, d_out, cols * 8 * n * 8, hipMemcpyDeviceToHost));
+    return P2_OK;
+}
+int p2_gpu_merkle_cap(const uint64_t* cols_major, size_t cols, size_t num_leaves, int cap_height, uint64_t* cap, int device) {
+    u32 bits = 0;
+    while (((size_t)1 << bits) < num_leaves) bits++;
+    if (((size_t)1 << bits) != num_leaves || (int)bits < cap_height) return set_error("num_leaves must be a power of two >= 2^cap_height"), P2_ERR_INVALID;
+    PrimCtx ctx;
+    if (int rc = ctx.init(device, 4)) return rc;
+    p2_circuit* C = &ctx.C;
+    C->c.cfg.cap_height = (u32)cap_height;
+    u64* d_in;
+    Tree t;
+    t.bits = bits;
+    if (upload(C, &d_in, cols_major, cols * num_leaves) || dalloc(C, &t.dig, t.stride())) return P2_ERR_HIP;
+    if (merkle_build(C, d_in, (u32)cols, (u32)cols, num_leaves, 0, t, 1)) return P2_ERR_HIP;
+    HIPCHECK(hipStreamSynchronize(C->stream));
+    HIPCHECK(hipMemcpy(cap, t.dig + cap_off(t, (u32)cap_height), ((size_t)4 << cap_height) * 8, hipMemcpyDeviceToHost));
+    return P2_OK;
+}
+}

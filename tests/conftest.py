@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    import __graft_entry__ as g
+    if not os.path.exists(g.LIB):
+        g.build()
+    return g.load_package()
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import oracle_lib
+    oracle_lib.lib()
+    return oracle_lib
