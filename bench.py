@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: proofs/sec on the AES-GCM 1 KiB circuit (BASELINE.json configs[2]).
+
+A "step" is one pass of the hot path -- p2_prove_batch_device: witness generation, commitments, quotient, FRI --
+over one batch of synthetic PartialWitness inputs that are already resident in HBM.  One process per GPU; with
+N > 1 each rank proves its own shard of independent proofs (no data-path collective), weak scaling.
+Prints ONE JSON line (rank 0).  Only the cpu_baseline leg touches oracle/.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def splitmix64(seed):
+    """SplitMix64 byte stream (proof i uses seed 0x5EED + i)."""
+    x = seed & 0xFFFFFFFFFFFFFFFF
+    while True:
+        x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        z ^= z >> 31
+        for k in range(8):
+            yield (z >> (8 * k)) & 0xFF
+
+
+def synth_inputs(pkg, target, index, L):
+    g = splitmix64(0x5EED + index)
+    key = bytes(next(g) for _ in range(16))
+    nonce = bytes(next(g) for _ in range(12))
+    pt = bytes(next(g) for _ in range(L))
+    ct, tag = pkg.native.gcm_encrypt(key, nonce, pt)
+    pw = pkg.PartialWitness()
+    target.set_targets(pw, key, nonce, pt, ct, tag)
+    return pw
+
+
+def kernel_bytes(name, info, active_wires=80):
+    """Algorithmic HBM bytes of ONE launch of a kernel, per proof (DESIGN.md 'Kernels')."""
+    n = 1 << info["degree_bits"]
+    N = 8 * n
+    if name == "hash_leaves":  # dominant launch = the wires tree: 80 live columns read once + digests written
+        return 8 * N * active_wires + 32 * N
+    if name == "lde":
+        return 8 * n * active_wires + 8 * N * active_wires
+    if name == "quotient":
+        return 8 * N * (80 + info["num_constants_cols"] + 80 + info["num_zs_cols"] + 16) + 16 * N
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="proofs per step per GPU")
+    ap.add_argument("--plaintext-bytes", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2, help="proofs timed on the host for cpu_baseline")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    lib = pkg.lib()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the prover has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    L, B = args.plaintext_bytes, args.batch
+    builder = pkg.CircuitBuilder()
+    target = pkg.AesGcmTarget.build(builder, 4, 10, L, False)  # AesGcm128Target<L>, aes-gcm/src/lib.rs:19
+    data = pkg.CircuitData(builder.build().blob, device=local_rank)
+    info = data.info
+    h = data.gpu()
+    pb = data.proof_bytes
+
+    # synthetic witnesses: rank r proves proofs [r*B, (r+1)*B); inputs are placed in HBM before the timed region
+    pws = [synth_inputs(pkg, target, rank * B + i, L) for i in range(B)]
+    targets = list(pws[0].map.keys())
+    nt = len(targets)
+    vals = torch.tensor([[pw.map[t] - (1 << 64) if pw.map[t] >= (1 << 63) else pw.map[t] for t in targets] for pw in pws],
+                        dtype=torch.int64, device="cuda")
+    proofs = torch.zeros(B * pb, dtype=torch.uint8, device="cuda")
+    status = torch.zeros(B, dtype=torch.int32, device="cuda")
+    tarr = (C.c_uint64 * nt)(*targets)
+
+    def step():
+        rc = lib.p2_prove_batch_device(h, B, tarr, nt, vals.data_ptr(), proofs.data_ptr(), status.data_ptr(), None)
+        if rc:
+            raise RuntimeError(lib.p2_last_error().decode())
+
+    def sync():
+        if lib.p2_circuit_synchronize(h):
+            raise RuntimeError(lib.p2_last_error().decode())
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    assert int(status.abs().sum().item()) == 0, "warm-up proofs failed: %s" % status.tolist()
+    if dist:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    if dist:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert int(status.abs().sum().item()) == 0
+
+    # per-kernel launch durations, measured live with HIP events on the proving stream (separate, untimed pass)
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        lib.p2_circuit_set_timing(h, 1)
+        step()
+        sync()
+        arr = (pkg.api._KernelTime * 64)()
+        k = lib.p2_circuit_get_timing(h, arr, 64)
+        lib.p2_circuit_set_timing(h, 0)
+        for i in range(min(k, 64)):
+            kernels[arr[i].name.decode()] = (arr[i].ms, arr[i].count)
+        total = sum(ms for ms, _ in kernels.values())
+        dom = max(kernels, key=lambda n: kernels[n][0])
+        ms, cnt = kernels[dom]
+        chunk = min(B, 32)
+        if dom == "hash_leaves":
+            # launches per chunk: wires (80 live cols), zs (34), quotient (16) trees -> algorithmic bytes averaged
+            n, N = 1 << info["degree_bits"], 8 << info["degree_bits"]
+            per_chunk = sum(8 * N * c + 32 * N for c in (80, info["num_zs_cols"], info["num_quotient_cols"])) * chunk
+            nbytes = per_chunk / 3.0
+        else:
+            kb = kernel_bytes(dom, info)
+            nbytes = kb * chunk if kb else None
+        avg_ms = ms / cnt
+        if nbytes:
+            ach = nbytes / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                        "share_of_gpu_time": round(ms / total, 3)}
+
+    cpu_baseline = None
+    if rank == 0 and not args.no_cpu_baseline:
+        import oracle_lib  # the checker, used here only as the reported CPU baseline
+        oc = oracle_lib.OracleCircuit(data.blob)
+        t1 = time.perf_counter()
+        for i in range(args.cpu_sample):
+            st, ref = oc.prove(pws[i].map)
+            assert st == 0
+        cdt = time.perf_counter() - t1
+        got = bytes(proofs[: args.cpu_sample * pb].cpu().numpy().tobytes())
+        assert got[(args.cpu_sample - 1) * pb: args.cpu_sample * pb] == ref, "GPU proof differs from the oracle's"
+        cpu_baseline = {"value": round(args.cpu_sample / cdt, 4), "unit": "proofs/s", "cores": oracle_lib.lib().orc_num_threads(),
+                        "kind": "port", "sample": "%d proofs of the same AES-GCM-128 L=%d workload (C++ restatement, OpenMP; not the Rust reference)" % (args.cpu_sample, L)}
+
+    if rank == 0:
+        total_proofs = B * args.steps * world
+        out = {
+            "metric": "proofs/sec (AES-GCM 1 KiB circuit)", "value": round(total_proofs / dt, 3), "unit": "proofs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks field)", "data": "synthetic",
+            "config": {"workload": "AES-GCM-128 %d-byte plaintext circuit (AesGcm128Target<%d>, TAG=false), n=2^%d rows, standard_recursion_config"
+                       % (L, L, info["degree_bits"]), "proofs_per_step_per_gpu": B, "proof_bytes": pb, "parallelism": "independent proofs sharded by index"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "kernels_ms_per_step": {k: round(v[0], 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1][0])},
+        }
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -300,7 +300,7 @@ __global__ void k_fill_wires(const int32_t* __restrict__ wire_slot, const u64* _
         v = values[(size_t)blockIdx.y * num_slots + s];
         if (v == UNSET) {
             v = 0;
-            atomicMax(&status[blockIdx.y], 2);
+            atomicCAS(&status[blockIdx.y], 0, 2);  // a conflict / lookup miss (1) already recorded wins
         }
     }
     wires[(size_t)blockIdx.y * wires_batch_stride + idx] = v;
