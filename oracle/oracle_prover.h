@@ -183,9 +183,16 @@ static inline int generate_witness(const OCircuit& C, const u64* in_targets, con
     };
     for (size_t i = 0; i < n_in; i++) {
         u64 t = in_targets[i];
-        if (t >= C.vt_slot.size() || C.vt_slot[t] < 0) return 1;
+        int32_t slot = -1;
+        if (t >> 63) {  // Target::Wire(row, column): routed wires only
+            u64 row = (t & ~(1ull << 63)) >> 8, col = t & 0xFF;
+            if (row < C.n && col < C.cfg.num_routed_wires) slot = C.wire_slot[col * C.n + row];
+        } else if (t < C.vt_slot.size()) {
+            slot = C.vt_slot[t];
+        }
+        if (slot < 0) return 1;
         if (in_values[i] >= MODULUS) return 1;
-        if (!set((u32)C.vt_slot[t], in_values[i])) return 1;
+        if (!set((u32)slot, in_values[i])) return 1;
     }
     for (const OOp& o : C.ops) {
         u64 r;

@@ -795,8 +795,16 @@ int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets,
     HIPCHECK(hipSetDevice(C->device));
     std::vector<u32> slots(n_targets);
     for (size_t i = 0; i < n_targets; i++) {
-        if (targets[i] >= C->c.vt_slot.size() || C->c.vt_slot[targets[i]] < 0) return set_error("input target is not a virtual target of this circuit"), P2_ERR_INVALID;
-        slots[i] = (u32)C->c.vt_slot[targets[i]];
+        u64 t = targets[i];
+        int32_t slot = -1;
+        if (t >> 63) {  // Target::Wire(row, column)
+            u64 row = (t & ~(1ull << 63)) >> 8, col = t & 0xFF;
+            if (row < C->n && col < C->c.cfg.num_routed_wires) slot = C->c.wire_slot[col * C->n + row];
+        } else if (t < C->c.vt_slot.size()) {
+            slot = C->c.vt_slot[t];
+        }
+        if (slot < 0) return set_error("input target is not a target of this circuit"), P2_ERR_INVALID;
+        slots[i] = (u32)slot;
     }
     size_t chunk = C->chunk ? C->chunk : std::min<size_t>(std::max<size_t>(batch, 1), 32);
     if (alloc_workspace(C, chunk, (u32)n_targets)) return P2_ERR_HIP;

@@ -1,0 +1,235 @@
+"""Circuit + witness constructors that mirror the reference's own circuit tests one for one.
+
+Each function returns (CircuitData, [PartialWitness, ...]) with the expected outputs written into the witness as
+well as the inputs -- the reference's correctness mechanism: a wrong expected value makes
+witness generation fail, i.e. `data.prove(pw)` is Err.
+"""
+import random
+
+SBOX = None
+
+
+def _sbox(orc):
+    global SBOX
+    if SBOX is None:
+        SBOX = [orc.lib().orc_sbox(x) for x in range(256)]
+    return SBOX
+
+
+def st_index(i, j):  # StateTarget.0[i][j] <-> flat 4*i + j
+    return 4 * i + j
+
+
+def assert_byte(pkg, values):  # aes-gcm/src/circuit_aes.rs:385 test_assert_byte
+    b = pkg.CircuitBuilder()
+    lut = b.sbox_lut()
+    t = b.add_virtual_byte_target(lut)
+    data = b.build()
+    pws = []
+    for v in values:
+        pw = pkg.PartialWitness()
+        pw.set_target(t, v)
+        pws.append(pw)
+    return data, pws
+
+
+def sub_bytes(pkg, orc, states):  # circuit_aes.rs:414 test_sub_bytes
+    b = pkg.CircuitBuilder()
+    s = b.add_virtual_state_target_unsafe()
+    lut = b.sbox_lut()
+    out = b.state_sub_bytes(lut, s)
+    data = b.build()
+    S = _sbox(orc)
+    pws = []
+    for st in states:
+        pw = pkg.PartialWitness()
+        pw.set_state_target(s, st)
+        pw.set_state_target(out, [S[x] for x in st])
+        pws.append(pw)
+    return data, pws
+
+
+def _mix_columns_native(pkg, st):
+    g = pkg.native.gf_2_8_mul
+    s = [[st[st_index(i, j)] for j in range(4)] for i in range(4)]
+    r = [[0] * 4 for _ in range(4)]
+    for c in range(4):
+        r[0][c] = g(2, s[0][c]) ^ g(3, s[1][c]) ^ s[2][c] ^ s[3][c]
+        r[1][c] = s[0][c] ^ g(2, s[1][c]) ^ g(3, s[2][c]) ^ s[3][c]
+        r[2][c] = s[0][c] ^ s[1][c] ^ g(2, s[2][c]) ^ g(3, s[3][c])
+        r[3][c] = g(3, s[0][c]) ^ s[1][c] ^ s[2][c] ^ g(2, s[3][c])
+    return [r[i][j] for i in range(4) for j in range(4)]
+
+
+def mix_columns(pkg, states):  # circuit_aes.rs:442 test_mix_columns
+    b = pkg.CircuitBuilder()
+    xl, ml = b.byte_xor_lut(), b.gf_2_8_mul_lut()
+    s = b.add_virtual_state_target_unsafe()
+    out = b.state_mix_columns(xl, ml, s)
+    data = b.build()
+    pws = []
+    for st in states:
+        pw = pkg.PartialWitness()
+        pw.set_state_target(s, st)
+        pw.set_state_target(out, _mix_columns_native(pkg, st))
+        pws.append(pw)
+    return data, pws
+
+
+def gf_2_8_mul(pkg, triples):  # circuit_aes.rs:473 test_gf_2_8_mul
+    b = pkg.CircuitBuilder()
+    lut = b.gf_2_8_mul_lut()
+    x, y = b.add_virtual_byte_target_unsafe(), b.add_virtual_byte_target_unsafe()
+    xy = b.gf_2_8_mul(lut, x, y)
+    data = b.build()
+    pws = []
+    for a, c, e in triples:
+        pw = pkg.PartialWitness()
+        pw.set_byte_target(x, a)
+        pw.set_byte_target(y, c)
+        pw.set_byte_target(xy, e)
+        pws.append(pw)
+    return data, pws
+
+
+def gf_2_8_add(pkg, pairs):  # circuit_aes.rs:513 test_gf_2_8_add
+    b = pkg.CircuitBuilder()
+    lut = b.byte_xor_lut()
+    x, y = b.add_virtual_byte_target_unsafe(), b.add_virtual_byte_target_unsafe()
+    xy = b.gf_2_8_add(lut, x, y)
+    data = b.build()
+    pws = []
+    for a, c in pairs:
+        pw = pkg.PartialWitness()
+        pw.set_byte_target(x, a)
+        pw.set_byte_target(y, c)
+        pw.set_byte_target(xy, a ^ c)
+        pws.append(pw)
+    return data, pws
+
+
+def key_expansion(pkg, key):  # circuit_aes.rs:548 test_key_expansion
+    nk = len(key) // 4
+    nr = nk + 6
+    b = pkg.CircuitBuilder()
+    kt = [b.add_virtual_byte_target_unsafe() for _ in range(4 * nk)]
+    xl, sl = b.byte_xor_lut(), b.sbox_lut()
+    ek = b.key_expansion(nk, nr, xl, sl, kt)
+    data = b.build()
+    w = pkg.native.key_expansion(key)
+    pw = pkg.PartialWitness()
+    for t, v in zip(kt, key):
+        pw.set_byte_target(t, v)
+    for t, v in zip(ek, w):
+        pw.set_byte_target(t, v)
+    return data, [pw]
+
+
+def encrypt_block(pkg, key, block, expected=None):  # circuit_aes.rs:619 test_encrypt_block_test_vector
+    nk = len(key) // 4
+    nr = nk + 6
+    b = pkg.CircuitBuilder()
+    kt = [b.add_virtual_byte_target_unsafe() for _ in range(4 * nk)]
+    xl, ml, sl = b.byte_xor_lut(), b.gf_2_8_mul_lut(), b.sbox_lut()
+    ek = b.key_expansion(nk, nr, xl, sl, kt)
+    ist = b.add_virtual_state_target(sl)
+    out = b.encrypt_block(nr, xl, ml, sl, ist, ek)
+    data = b.build()
+    ct = expected if expected is not None else pkg.native.encrypt_block(key, block)
+    w = pkg.native.key_expansion(key)
+    pw = pkg.PartialWitness()
+    for t, v in zip(kt, key):
+        pw.set_byte_target(t, v)
+    pw.set_state_target(ist, [block[i + 4 * j] for i in range(4) for j in range(4)])
+    for t, v in zip(ek, w):
+        pw.set_byte_target(t, v)
+    pw.set_state_target(out, [ct[i + 4 * j] for i in range(4) for j in range(4)])
+    return data, [pw]
+
+
+def right_shift_one(pkg):  # circuit_gcm.rs:537 test_right_shift_one
+    x = [111] * 16
+    exp, carry = [], 0
+    for v in x:
+        exp.append((v >> 1) | (carry << 7))
+        carry = v & 1
+    b = pkg.CircuitBuilder()
+    lut = b.u8_unit_right_shift_lut()
+    xt = [b.add_virtual_byte_target_unsafe() for _ in range(16)]
+    out = b.right_shift_one(lut, xt)
+    data = b.build()
+    pw = pkg.PartialWitness()
+    for t, v in zip(xt, x):
+        pw.set_byte_target(t, v)
+    for t, v in zip(out, exp):
+        pw.set_byte_target(t, v)
+    return data, [pw]
+
+
+def gctr(pkg, nk, L):  # circuit_gcm.rs:460 test_gctr
+    nr = nk + 6
+    key, icb, pt = bytes([42] * (4 * nk)), bytes([222] * 16), bytes([42] * L)
+    b = pkg.CircuitBuilder()
+    kt = [b.add_virtual_byte_target_unsafe() for _ in range(4 * nk)]
+    it = [b.add_virtual_byte_target_unsafe() for _ in range(16)]
+    pt_t = [b.add_virtual_byte_target_unsafe() for _ in range(L)]
+    sl, xl, ml = b.sbox_lut(), b.byte_xor_lut(), b.gf_2_8_mul_lut()
+    ek = b.key_expansion(nk, nr, xl, sl, kt)
+    out = b.gctr(nr, xl, ml, sl, ek, it, pt_t)
+    data = b.build()
+    exp = pkg.native.gctr(key, icb, pt)
+    pw = pkg.PartialWitness()
+    for ts, vs in ((kt, key), (it, icb), (pt_t, pt), (out, exp)):
+        for t, v in zip(ts, vs):
+            pw.set_byte_target(t, v)
+    return data, [pw]
+
+
+def gf_2_128_mul(pkg):  # circuit_gcm.rs:570 test_gf_mul
+    x, y = bytes([111] * 16), bytes([222] * 16)
+    b = pkg.CircuitBuilder()
+    xl, shl, brl = b.byte_xor_lut(), b.u8_unit_right_shift_lut(), b.u8_bitref_lut()
+    xt = [b.add_virtual_byte_target_unsafe() for _ in range(16)]
+    yt = [b.add_virtual_byte_target_unsafe() for _ in range(16)]
+    out = b.gf_2_128_mul(xl, shl, brl, xt, yt)
+    data = b.build()
+    exp = pkg.native.gf_2_128_mul(x, y)
+    pw = pkg.PartialWitness()
+    for ts, vs in ((xt, x), (yt, y), (out, exp)):
+        for t, v in zip(ts, vs):
+            pw.set_byte_target(t, v)
+    return data, [pw]
+
+
+def ghash(pkg, L):  # circuit_gcm.rs:635 test_ghash
+    h, x = bytes([222] * 16), bytes([42] * L)
+    b = pkg.CircuitBuilder()
+    xl, shl, brl = b.byte_xor_lut(), b.u8_unit_right_shift_lut(), b.u8_bitref_lut()
+    ht = [b.add_virtual_byte_target_unsafe() for _ in range(16)]
+    xt = [b.add_virtual_byte_target_unsafe() for _ in range(L)]
+    out = b.ghash(xl, shl, brl, ht, xt)
+    data = b.build()
+    exp = pkg.native.ghash(h, x)
+    pw = pkg.PartialWitness()
+    for ts, vs in ((ht, h), (xt, x), (out, exp)):
+        for t, v in zip(ts, vs):
+            pw.set_byte_target(t, v)
+    return data, [pw]
+
+
+def encrypt(pkg, nk, L, tag, keys=None):  # circuit_gcm.rs:695 test_encrypt (key [42;..], nonce [111;12], pt [42;L])
+    b = pkg.CircuitBuilder()
+    t = pkg.AesGcmTarget.build(b, nk, nk + 6, L, tag)
+    data = b.build()
+    pws = []
+    for key, nonce, pt in (keys or [(bytes([42] * (4 * nk)), bytes([111] * 12), bytes([42] * L))]):
+        ct, tg = pkg.native.gcm_encrypt(key, nonce, pt)
+        pw = pkg.PartialWitness()
+        t.set_targets(pw, key, nonce, pt, ct, tg)
+        pws.append(pw)
+    return data, pws, t
+
+
+def random_states(seed, count):
+    r = random.Random(seed)
+    return [[r.randrange(256) for _ in range(16)] for _ in range(count)]

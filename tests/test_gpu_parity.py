@@ -1,0 +1,210 @@
+"""GPU parity tests (pytest -m gpu): the HIP path through the C ABI against the CPU oracle, bit for bit.
+
+Integer/field work => the bar is exact equality of every buffer and of the serialised proof bytes."""
+import ctypes as C
+import hashlib
+import json
+import os
+import random
+
+import pytest
+
+import circuits
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpu(pkg):
+    if pkg.lib().p2_gpu_device_count() <= 0:
+        pytest.fail("-m gpu tests need a GPU: the HIP path has no CPU fallback")
+    return pkg
+
+
+def test_native_library_is_the_in_tree_hip_build(gpu):
+    path = gpu.lib_path()
+    assert path.startswith(ROOT) and os.path.exists(path)
+    maps = open("/proc/self/maps").read()
+    assert "libp2aes.so" in maps
+
+
+def test_poseidon_permutation(gpu, orc):
+    r = random.Random(11)
+    n = 5000
+    edge = [0] * 12 + [P - 1] * 12 + list(range(12))
+    st = edge + [r.randrange(P) for _ in range(12 * n - len(edge))]
+    buf = (C.c_uint64 * len(st))(*st)
+    assert gpu.lib().p2_gpu_poseidon(buf, n, 0) == 0
+    assert buf[0] == 0x3C18A9786CB0B359     # upstream test vector, all-zero input
+    for i in list(range(3)) + [r.randrange(n) for _ in range(300)]:
+        s = (C.c_uint64 * 12)(*st[12 * i:12 * i + 12])
+        orc.lib().orc_poseidon(s)
+        assert list(s) == list(buf[12 * i:12 * i + 12])
+
+
+@pytest.mark.parametrize("bits", [1, 2, 4, 7, 11, 14])
+def test_intt_and_lde(gpu, orc, bits):
+    r = random.Random(bits)
+    cols, n = 5, 1 << bits
+    vals = [r.randrange(P) for _ in range(cols * n)]
+    vals[:n] = [0] * n                       # an all-zero column
+    vals[n:2 * n] = [P - 1] * n              # and a saturated one
+    arr = (C.c_uint64 * len(vals))(*vals)
+    out = (C.c_uint64 * len(vals))()
+    assert gpu.lib().p2_gpu_intt(arr, cols, bits, out, 0) == 0, gpu.lib().p2_last_error()
+    lde = (C.c_uint64 * (8 * len(vals)))()
+    assert gpu.lib().p2_gpu_lde(arr, cols, bits, 3, lde, 0) == 0, gpu.lib().p2_last_error()
+    for c in range(cols):
+        a = (C.c_uint64 * n)(*vals[c * n:(c + 1) * n])
+        orc.lib().orc_fft(a, bits, 1)
+        assert list(a) == list(out[c * n:(c + 1) * n])
+        o = (C.c_uint64 * (8 * n))()
+        orc.lib().orc_lde((C.c_uint64 * n)(*vals[c * n:(c + 1) * n]), bits, 3, o)
+        assert list(o) == list(lde[c * 8 * n:(c + 1) * 8 * n])
+
+
+def test_intt_rejects_unsupported_sizes(gpu):
+    arr = (C.c_uint64 * 4)()
+    assert gpu.lib().p2_gpu_intt(arr, 1, 0, arr, 0) != 0
+    assert gpu.lib().p2_gpu_intt(arr, 1, 15, arr, 0) != 0
+
+
+@pytest.mark.parametrize("cols,leaves", [(1, 16), (4, 32), (5, 64), (8, 128), (9, 256), (135, 1024)])
+def test_merkle_cap(gpu, orc, cols, leaves):
+    r = random.Random(cols)
+    colmaj = [r.randrange(P) for _ in range(cols * leaves)]
+    cap = (C.c_uint64 * 64)()
+    assert gpu.lib().p2_gpu_merkle_cap((C.c_uint64 * len(colmaj))(*colmaj), cols, leaves, 4, cap, 0) == 0
+    rowmaj = [colmaj[c * leaves + i] for i in range(leaves) for c in range(cols)]
+    ref = (C.c_uint64 * 64)()
+    orc.lib().orc_merkle_cap((C.c_uint64 * len(rowmaj))(*rowmaj), leaves, cols, 4, ref)
+    assert list(cap) == list(ref)
+
+
+def _gpu_vs_oracle(gpu, orc, data, pws):
+    oc = orc.OracleCircuit(data.blob)
+    assert data.verifier_data() == oc.verifier_data()
+    proofs, status = data.prove_batch(pws)
+    for pw, proof, st in zip(pws, proofs, status):
+        ost, ref = oc.prove(pw.map)
+        assert st == ost
+        if ost == 0:
+            assert proof == ref
+            data.verify(proof)
+    return proofs, status
+
+
+def test_assert_byte_error_convention(gpu, orc):
+    # circuit_aes.rs:396-410: bytes prove and verify; tv > 255 => prove is Err (never a bad proof, never a crash)
+    data, pws = circuits.assert_byte(gpu, [0, 255, 256, 0xFFFFFFFF00000000, 70000, 17])
+    proofs, status = _gpu_vs_oracle(gpu, orc, data, pws)
+    assert status == [0, 0, 1, 1, 1, 0]
+    assert proofs[2] is None
+    with pytest.raises(gpu.ProveError):
+        data.prove(pws[2])
+
+
+def test_missing_and_conflicting_inputs(gpu, orc):
+    data, pws = circuits.sub_bytes(gpu, orc, circuits.random_states(4, 3))
+    bad = gpu.PartialWitness()
+    bad.map = dict(pws[1].map)
+    k = list(bad.map)[-1]
+    bad.map[k] ^= 1                          # wrong expected output -> conflict
+    proofs, status = _gpu_vs_oracle(gpu, orc, data, [pws[0], bad, pws[2]])
+    assert status == [0, 1, 0]
+    missing = gpu.PartialWitness()
+    missing.map = dict(pws[0].map)
+    del missing.map[list(missing.map)[0]]    # an input never set -> a generator never runs
+    assert data.prove_batch([missing])[1] == [2]
+    other = gpu.PartialWitness()
+    other.set_target(10 ** 9, 1)
+    with pytest.raises(gpu.P2Error):
+        data.prove_batch([other])            # not a target of this circuit
+
+
+@pytest.mark.parametrize("name", ["mix_columns", "gf_2_8_mul", "gf_2_8_add", "key_expansion_128", "encrypt_block_fips197",
+                                  "right_shift_one", "gctr_128_17", "gf_2_128_mul", "ghash_32", "encrypt_128_13",
+                                  "encrypt_128_13_tag", "encrypt_128_17", "encrypt_192_13", "encrypt_256_13_tag"])
+def test_reference_circuit_tests_bit_exact(gpu, orc, name):
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "aes_kat.json")))
+    kat_key = bytes.fromhex(kat["fips197_block"]["key"])
+    if name == "mix_columns":
+        data, pws = circuits.mix_columns(gpu, circuits.random_states(2, 3))
+    elif name == "gf_2_8_mul":
+        data, pws = circuits.gf_2_8_mul(gpu, kat["gf_2_8_mul"])
+    elif name == "gf_2_8_add":
+        data, pws = circuits.gf_2_8_add(gpu, [(0xA5, 0x3C), (0, 0), (255, 255)])
+    elif name == "key_expansion_128":
+        data, pws = circuits.key_expansion(gpu, kat_key)
+    elif name == "encrypt_block_fips197":
+        data, pws = circuits.encrypt_block(gpu, kat_key, bytes.fromhex(kat["fips197_block"]["input"]),
+                                           expected=bytes.fromhex(kat["fips197_block"]["output"]))
+    elif name == "right_shift_one":
+        data, pws = circuits.right_shift_one(gpu)
+    elif name == "gctr_128_17":
+        data, pws = circuits.gctr(gpu, 4, 17)
+    elif name == "gf_2_128_mul":
+        data, pws = circuits.gf_2_128_mul(gpu)
+    elif name == "ghash_32":
+        data, pws = circuits.ghash(gpu, 32)
+    elif name == "encrypt_128_13":
+        data, pws, _ = circuits.encrypt(gpu, 4, 13, False)
+    elif name == "encrypt_128_13_tag":
+        data, pws, _ = circuits.encrypt(gpu, 4, 13, True)
+    elif name == "encrypt_128_17":
+        data, pws, _ = circuits.encrypt(gpu, 4, 17, False)
+    elif name == "encrypt_192_13":
+        data, pws, _ = circuits.encrypt(gpu, 6, 13, False)
+    else:
+        data, pws, _ = circuits.encrypt(gpu, 8, 13, True)
+    _gpu_vs_oracle(gpu, orc, data, pws[:2])
+
+
+def test_cavp_vectors_in_circuit(gpu, orc):
+    # the NIST CAVP vectors of native_gcm.rs:290-329 pushed through the circuit (pt lengths 16 and 13, with tag)
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "aes_kat.json")))
+    for v in kat["cavp_gcm128"][1:3]:
+        key, iv, pt, ct, tag = (bytes.fromhex(v[k]) for k in ("key", "iv", "pt", "ct", "tag"))
+        b = gpu.CircuitBuilder()
+        t = gpu.AesGcmTarget.build(b, 4, 10, len(pt), True)
+        data = b.build()
+        pw = gpu.PartialWitness()
+        t.set_targets(pw, key, iv, pt, ct, tag)
+        proof = data.prove(pw)
+        data.verify(proof)
+        wrong = gpu.PartialWitness()
+        t.set_targets(wrong, key, iv, pt, ct, bytes([tag[0] ^ 1]) + tag[1:])
+        with pytest.raises(gpu.ProveError):
+            data.prove(wrong)
+
+
+def test_full_size_aes_gcm_1kib_batch(gpu, orc):
+    """BASELINE.json configs[2] at full size: a batch larger than one chunk, distinct witnesses.
+    Size-independent properties: every proof verifies; proving is deterministic; distinct witnesses give distinct
+    proofs; and one proof of the batch is compared byte for byte with the oracle."""
+    r = random.Random(99)
+    L = 1024
+    keys = [(bytes(r.randrange(256) for _ in range(16)), bytes(r.randrange(256) for _ in range(12)), bytes(r.randrange(256) for _ in range(L)))
+            for _ in range(35)]
+    data, pws, _ = circuits.encrypt(gpu, 4, L, False, keys=keys)
+    assert data.info["degree_bits"] == 14
+    proofs, status = data.prove_batch(pws)
+    assert status == [0] * len(pws)
+    vd = data.verifier_data()
+    for p in proofs:
+        data.verify(p, vd)
+    assert len({hashlib.sha256(p).digest() for p in proofs}) == len(proofs)
+    again, _ = data.prove_batch(pws[30:35])
+    assert again == proofs[30:35]                      # deterministic, independent of position in the batch/chunk
+    oc = orc.OracleCircuit(data.blob)
+    st, ref = oc.prove(pws[33].map)
+    assert st == 0 and ref == proofs[33]
+    # a wrong ciphertext byte in one witness fails that proof only
+    bad = gpu.PartialWitness()
+    bad.map = dict(pws[1].map)
+    k = [t for t in bad.map][16 + 12 + L + 5]
+    bad.map[k] ^= 0x10
+    proofs2, status2 = data.prove_batch([pws[0], bad, pws[2]])
+    assert status2 == [0, 1, 0] and proofs2[0] == proofs[0] and proofs2[2] == proofs[2]

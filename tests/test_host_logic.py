@@ -1,0 +1,202 @@
+"""CPU tests of the host layer: C-ABI surface, builder behaviour, blob handling, verifier, and the oracle -> verifier
+loop on the reference's own circuit tests (accept / reject behaviour is what those tests pin)."""
+import ctypes as C
+import hashlib
+import os
+import re
+
+import pytest
+
+import circuits
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "p2aes.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(p2_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"p2_builder", "p2_circuit"}
+    lib = C.CDLL(pkg.lib_path())
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert len(declared) >= 60
+    assert not pkg.lib()._p2_missing
+
+
+def test_prove_without_gpu_fails_loudly(pkg):
+    if pkg.lib().p2_gpu_device_count() > 0:
+        pytest.skip("a GPU is present")
+    data, pws = circuits.assert_byte(pkg, [3])
+    with pytest.raises(pkg.P2Error, match="no HIP device"):
+        data.prove(pws[0])
+
+
+def test_builder_constant_folding_and_caching(pkg):
+    b = pkg.CircuitBuilder()
+    x, y = b.add_virtual_target(), b.add_virtual_target()
+    z = b.zero()
+    assert b.constant(5) == b.constant(5)
+    assert b.mul_const_add(256, z, y) == y          # first term zero, const_1 == 1 -> addend (arithmetic_special_cases)
+    assert b.mul(b.one(), x) == x                   # 1 * x
+    assert b.add(b.constant(2), b.constant(3)) == b.constant(5)
+    g0 = b.num_gates()
+    r1 = b.mul_const_add(256, x, y)
+    assert b.num_gates() == g0 + 1
+    assert b.mul_const_add(256, x, y) == r1 and b.num_gates() == g0 + 1   # base_arithmetic_results cache
+    for _ in range(19):
+        b.mul_const_add(256, b.add_virtual_target(), y)
+    assert b.num_gates() == g0 + 1                  # 20 ops share one ArithmeticGate row
+    b.mul_const_add(256, b.add_virtual_target(), y)
+    assert b.num_gates() == g0 + 2
+    b.mul_const_add(8, x, y)
+    assert b.num_gates() == g0 + 3                  # different constants -> different row
+    assert b.add_lookup_table_from_pairs([(1, 2), (3, 4)]) == b.add_lookup_table_from_pairs([(1, 2), (3, 4)])
+    with pytest.raises(pkg.P2Error):
+        b.add_lookup_from_index(x, 7)
+
+
+def test_partial_witness_set_target_conflict(pkg):
+    pw = pkg.PartialWitness()
+    pw.set_target(1, 5)
+    pw.set_target(1, 5)
+    with pytest.raises(pkg.P2Error):
+        pw.set_target(1, 6)
+    with pytest.raises(pkg.P2Error):
+        pw.set_target(2, 0xFFFFFFFF00000001)
+
+
+def test_circuit_shapes(pkg):
+    # row counts of the reference's size-report configurations (circuit_gcm.rs:708-736 prints them, nothing is
+    # recorded upstream; these are this repo's own regression values)
+    data, _, _ = circuits.encrypt(pkg, 4, 1024, False)
+    assert data.info["degree_bits"] == 14 and data.info["num_luts"] == 3 and data.info["num_constants_cols"] == 10
+    assert data.info["num_zs_cols"] == 34 and data.info["num_quotient_cols"] == 16 and data.info["num_fri_rounds"] == 3
+    assert data.info["proof_bytes"] == 151132
+    data, _, _ = circuits.encrypt(pkg, 4, 13, True)
+    assert data.info["degree_bits"] == 13 and data.info["num_luts"] == 5
+    data, _ = circuits.assert_byte(pkg, [1])
+    assert data.info["degree_bits"] == 4 and data.info["num_fri_rounds"] == 0
+
+
+def test_blob_rejects_garbage(pkg):
+    data, _ = circuits.assert_byte(pkg, [1])
+    info = pkg.api._Info()
+    assert pkg.lib().p2_blob_info(b"nonsense", 8, C.byref(info)) != 0
+    assert pkg.lib().p2_blob_info(data.blob[:100], 100, C.byref(info)) != 0
+    bad = bytearray(data.blob)
+    bad[8] = 99  # version
+    assert pkg.lib().p2_blob_info(bytes(bad), len(bad), C.byref(info)) != 0
+
+
+def _prove_verify(pkg, orc, data, pws, expect_ok=True):
+    oc = orc.OracleCircuit(data.blob)
+    vd = oc.verifier_data()
+    out = []
+    for pw in pws:
+        st, proof = oc.prove(pw.map)
+        if expect_ok:
+            assert st == 0
+            assert len(proof) == data.proof_bytes
+            data.verify(proof, vd)
+        out.append((st, proof))
+    return oc, vd, out
+
+
+def test_assert_byte_accepts_bytes_rejects_others(pkg, orc):
+    data, pws = circuits.assert_byte(pkg, [0, 255, 256, 0xFFFFFFFF00000000, 70000])
+    oc = orc.OracleCircuit(data.blob)
+    sts = [oc.prove(pw.map)[0] for pw in pws]
+    assert sts == [0, 0, 1, 1, 1]          # circuit_aes.rs:403-405: tv > 255 => prove is Err
+
+
+def test_sub_bytes_and_negative(pkg, orc):
+    data, pws = circuits.sub_bytes(pkg, orc, circuits.random_states(1, 2))
+    oc, vd, res = _prove_verify(pkg, orc, data, pws)
+    bad = dict(pws[0].map)
+    k = list(bad)[-1]
+    bad[k] ^= 1
+    assert oc.prove(bad)[0] == 1
+    missing = dict(pws[0].map)
+    del missing[list(missing)[0]]
+    assert oc.prove(missing)[0] == 2
+
+
+def test_verifier_rejects_tampering(pkg, orc):
+    data, pws = circuits.gf_2_8_mul(pkg, [(0x57, 0x13, 0xFE)])
+    oc, vd, res = _prove_verify(pkg, orc, data, pws)
+    proof = res[0][1]
+    data.verify(proof, vd)
+    n = len(proof)
+    for pos in (0, 600, 1600, 4000, 5000, n // 2, n - 200, n - 9, n - 1):
+        bad = bytearray(proof)
+        bad[pos] ^= 1
+        with pytest.raises(pkg.P2Error):
+            data.verify(bytes(bad), vd)
+    with pytest.raises(pkg.P2Error):
+        data.verify(proof[:-1], vd)
+    with pytest.raises(pkg.P2Error):
+        data.verify(proof + b"\0", vd)
+    bad_vd = list(vd)
+    for k in range(16):  # every cap digest (a single one is only hit by ~1/16 of the 28 queries)
+        bad_vd[4 * k] ^= 1
+    with pytest.raises(pkg.P2Error):
+        data.verify(proof, bad_vd)
+    bad_vd = list(vd)
+    bad_vd[-1] ^= 1      # circuit digest feeds the transcript
+    with pytest.raises(pkg.P2Error):
+        data.verify(proof, bad_vd)
+    # a proof for one circuit does not verify against another
+    data2, pws2 = circuits.gf_2_8_add(pkg, [(1, 2)])
+    oc2 = orc.OracleCircuit(data2.blob)
+    with pytest.raises(pkg.P2Error):
+        data2.verify(proof, oc2.verifier_data())
+
+
+def test_gf_2_8_mul_all_reference_triples(pkg, orc):
+    import json
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "aes_kat.json")))
+    data, pws = circuits.gf_2_8_mul(pkg, kat["gf_2_8_mul"][-3:])
+    _prove_verify(pkg, orc, data, pws)
+    data, pws = circuits.gf_2_8_mul(pkg, [(0x57, 0x13, 0xFF)])
+    assert orc.OracleCircuit(data.blob).prove(pws[0].map)[0] == 1
+
+
+@pytest.mark.parametrize("name", ["mix_columns", "gf_2_8_add", "key_expansion_128", "encrypt_block_fips197", "right_shift_one",
+                                  "gctr_128_13", "gf_2_128_mul", "ghash_16", "encrypt_128_13", "encrypt_128_13_tag", "encrypt_128_17",
+                                  "encrypt_256_13"])
+def test_reference_circuit_tests(pkg, orc, name):
+    kat_key = bytes.fromhex("2b7e151628aed2a6abf7158809cf4f3c")
+    if name == "mix_columns":
+        data, pws = circuits.mix_columns(pkg, circuits.random_states(2, 1))
+    elif name == "gf_2_8_add":
+        data, pws = circuits.gf_2_8_add(pkg, [(0xA5, 0x3C)])
+    elif name == "key_expansion_128":
+        data, pws = circuits.key_expansion(pkg, kat_key)
+    elif name == "encrypt_block_fips197":
+        data, pws = circuits.encrypt_block(pkg, kat_key, bytes.fromhex("3243f6a8885a308d313198a2e0370734"),
+                                           expected=bytes.fromhex("3925841d02dc09fbdc118597196a0b32"))
+    elif name == "right_shift_one":
+        data, pws = circuits.right_shift_one(pkg)
+    elif name == "gctr_128_13":
+        data, pws = circuits.gctr(pkg, 4, 13)
+    elif name == "gf_2_128_mul":
+        data, pws = circuits.gf_2_128_mul(pkg)
+    elif name == "ghash_16":
+        data, pws = circuits.ghash(pkg, 16)
+    elif name == "encrypt_128_13":
+        data, pws, _ = circuits.encrypt(pkg, 4, 13, False)
+    elif name == "encrypt_128_13_tag":
+        data, pws, _ = circuits.encrypt(pkg, 4, 13, True)
+    elif name == "encrypt_128_17":
+        data, pws, _ = circuits.encrypt(pkg, 4, 17, False)
+    else:
+        data, pws, _ = circuits.encrypt(pkg, 8, 13, False)
+    _prove_verify(pkg, orc, data, pws)
+
+
+def test_oracle_proofs_are_deterministic(pkg, orc):
+    data, pws = circuits.gf_2_8_add(pkg, [(7, 9)])
+    oc = orc.OracleCircuit(data.blob)
+    a, b = oc.prove(pws[0].map)[1], oc.prove(pws[0].map)[1]
+    assert a == b and hashlib.sha256(a).hexdigest() == hashlib.sha256(b).hexdigest()

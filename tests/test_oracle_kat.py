@@ -1,0 +1,118 @@
+"""CPU tests: the oracle against every golden vector the reference's tests hold for this path, and against
+independent big-integer arithmetic; the product's native cipher against the same vectors."""
+import ctypes as C
+import json
+import os
+import random
+
+P = 0xFFFFFFFF00000001
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "aes_kat.json")))
+
+
+def test_oracle_field_vs_bigint(orc):
+    L, r = orc.lib(), random.Random(1)
+    xs = [0, 1, P - 1, P - 2, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFF00000000] + [r.randrange(P) for _ in range(200)]
+    for a in xs:
+        for b in xs[:12] + [r.randrange(P) for _ in range(8)]:
+            assert L.orc_fmul(a, b) == a * b % P
+            assert L.orc_fadd(a, b) == (a + b) % P
+            assert L.orc_fsub(a, b) == (a - b) % P
+    for a in xs[1:40]:
+        assert L.orc_fmul(L.orc_finv(a), a) == 1
+
+
+def test_poseidon_upstream_test_vector(orc):
+    # plonky2 poseidon_goldilocks.rs test_vectors: all-zero input (first and last words, SURVEY.md C.3 tripwire)
+    st = (C.c_uint64 * 12)()
+    orc.lib().orc_poseidon(st)
+    assert st[0] == 0x3C18A9786CB0B359 and st[1] == 0xC4055E3364A246C3 and st[11] == 0x1792B1C4342109D7
+
+
+def test_poseidon_constants_rederive():
+    # the committed .inc files are what tools/gen_poseidon_constants.py derives (ChaCha8 seed 0, rand-0.8 gen_range)
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(__file__))
+    spec = importlib.util.spec_from_file_location("gen", os.path.join(root, "tools", "gen_poseidon_constants.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    rc = gen.constants()
+    assert rc[0] == 0xB585F766F2144405 and rc[1] == 0x7746A55F43921AD7
+    for path in ("oracle/poseidon_rc.inc", "plonky2-aes_amd/csrc/poseidon_rc.inc"):
+        txt = open(os.path.join(root, path)).read()
+        got = [int(t.rstrip("ULL,"), 16) for t in txt.split() if t.startswith("0x")]
+        assert got == rc
+    assert gen.permute([0] * 12, rc)[0] == 0x3C18A9786CB0B359
+
+
+def test_oracle_fft_matches_naive_dft(orc):
+    r, bits = random.Random(2), 4
+    n = 1 << bits
+    w = pow(7277203076849721926, 1 << (32 - bits), P)
+    x = [r.randrange(P) for _ in range(n)]
+    a = (C.c_uint64 * n)(*x)
+    orc.lib().orc_fft(a, bits, 0)
+    assert list(a) == [sum(x[j] * pow(w, j * k, P) for j in range(n)) % P for k in range(n)]
+    orc.lib().orc_fft(a, bits, 1)
+    assert list(a) == x
+
+
+def test_oracle_lde_is_evaluation_on_coset(orc):
+    r, bits = random.Random(3), 3
+    n, N, g = 8, 64, 14293326489335486720
+    c = [r.randrange(P) for _ in range(n)]
+    out = (C.c_uint64 * N)()
+    orc.lib().orc_lde((C.c_uint64 * n)(*c), bits, 3, out)
+    w = pow(7277203076849721926, 1 << (32 - 6), P)
+    for i in range(N):
+        x = g * pow(w, i, P) % P
+        rev = int(format(i, "06b")[::-1], 2)
+        assert out[rev] == sum(ci * pow(x, k, P) for k, ci in enumerate(c)) % P
+
+
+def _both(pkg, orc):
+    return [("oracle", orc.encrypt_block, orc.gcm_encrypt), ("native", pkg.native.encrypt_block, pkg.native.gcm_encrypt)]
+
+
+def test_fips197_block(pkg, orc):
+    v = GOLD["fips197_block"]
+    for name, enc, _ in _both(pkg, orc):
+        assert enc(bytes.fromhex(v["key"]), bytes.fromhex(v["input"])).hex() == v["output"], name
+
+
+def test_key_expansion_prefix(pkg, orc):
+    for v in GOLD["key_expansion_prefix"]:
+        key = bytes.fromhex(v["key"])
+        nk = len(key) // 4
+        out = C.create_string_buffer(16 * (nk + 7))
+        orc.lib().orc_aes_expand_key(key, nk, out)
+        for w in (out.raw, pkg.native.key_expansion(key)):
+            assert [w[4 * i:4 * i + 4].hex() for i in range(nk)] == v["words"]
+        assert out.raw == pkg.native.key_expansion(key)
+
+
+def test_gf_2_8_products(pkg, orc):
+    for a, b, e in GOLD["gf_2_8_mul"]:
+        assert orc.lib().orc_gf_2_8_mul(a, b) == e and pkg.native.gf_2_8_mul(a, b) == e
+
+
+def test_cavp_gcm_vectors(pkg, orc):
+    for v in GOLD["cavp_gcm128"] + GOLD["derived_by_pinned_oracle"]:
+        for name, _, gcm in _both(pkg, orc):
+            ct, tag = gcm(bytes.fromhex(v["key"]), bytes.fromhex(v["iv"]), bytes.fromhex(v["pt"]))
+            assert ct.hex() == v["ct"] and tag.hex() == v["tag"], name
+
+
+def test_native_matches_oracle_random(pkg, orc):
+    # the reference's differential tests (native_gcm.rs:334-374) use these plaintext lengths, AES-128 and AES-256
+    r = random.Random(5)
+    for nk in (4, 6, 8):
+        for L in (0, 16, 32, 1, 17, 14, 26, 131, 1027, 4242):
+            key, iv, pt = bytes(r.randrange(256) for _ in range(4 * nk)), bytes(r.randrange(256) for _ in range(12)), bytes(r.randrange(256) for _ in range(L))
+            assert pkg.native.gcm_encrypt(key, iv, pt) == orc.gcm_encrypt(key, iv, pt)
+    x, y = bytes(r.randrange(256) for _ in range(16)), bytes(r.randrange(256) for _ in range(16))
+    o = C.create_string_buffer(16)
+    orc.lib().orc_gf_2_128_mul(x, y, o)
+    assert o.raw == pkg.native.gf_2_128_mul(x, y)
+    data = bytes(r.randrange(256) for _ in range(64))
+    orc.lib().orc_ghash(x, data, 64, o)
+    assert o.raw == pkg.native.ghash(x, data)
