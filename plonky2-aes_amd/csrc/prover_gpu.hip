@@ -698,7 +698,7 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
         C->c = deserialize(blob, len);
         const Circuit& c = C->c;
         if (c.cfg.rate_bits != 3 || c.cfg.num_challenges != 2 || c.cfg.quotient_degree_factor != 8 || c.cfg.num_routed_wires != 80 || c.cfg.arity_bits != 4 ||
-            c.cfg.num_query_rounds > 64 || c.gates.size() > 8 || c.luts.size() > 4)
+            c.cfg.num_query_rounds > 64 || c.gates.size() > 8 || c.luts.size() > 6)
             throw std::runtime_error("only CircuitConfig::standard_recursion_config() is supported");
         if (c.degree_bits > 14) throw std::runtime_error("degree_bits > 14 needs the multi-pass NTT (not built yet)");
         C->device = device;
