@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="proofs per step per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="proofs per step per GPU")
     ap.add_argument("--plaintext-bytes", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2, help="proofs timed on the host for cpu_baseline")
@@ -139,7 +139,9 @@ def main():
     kernels = {}
     if rank == 0:
         lib.p2_circuit_set_timing(h, 1)
-        step()
+        chunk = min(B, 32)
+        rc = lib.p2_prove_batch_device(h, chunk, tarr, nt, vals.data_ptr(), proofs.data_ptr(), status.data_ptr(), None)  # one chunk = one stream
+        assert rc == 0
         sync()
         arr = (pkg.api._KernelTime * 64)()
         k = lib.p2_circuit_get_timing(h, arr, 64)
@@ -149,7 +151,6 @@ def main():
         total = sum(ms for ms, _ in kernels.values())
         dom = max(kernels, key=lambda n: kernels[n][0])
         ms, cnt = kernels[dom]
-        chunk = min(B, 32)
         if dom == "hash_leaves":
             # launches per chunk: wires (80 live cols), zs (34), quotient (16) trees -> algorithmic bytes averaged
             n, N = 1 << info["degree_bits"], 8 << info["degree_bits"]
@@ -188,7 +189,7 @@ def main():
             "config": {"workload": "AES-GCM-128 %d-byte plaintext circuit (AesGcm128Target<%d>, TAG=false), n=2^%d rows, standard_recursion_config"
                        % (L, L, info["degree_bits"]), "proofs_per_step_per_gpu": B, "proof_bytes": pb, "parallelism": "independent proofs sharded by index"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
-            "kernels_ms_per_step": {k: round(v[0], 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1][0])},
+            "kernels_ms_per_chunk32": {k: round(v[0], 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1][0])},
         }
         print(json.dumps(out))
     if dist:

@@ -11,6 +11,7 @@
 
 #include "circuit.h"
 #include "gl.h"
+#include "poseidon_fast.h"
 
 namespace p2k {
 using gl::E2;
@@ -22,7 +23,7 @@ static const u64 UNSET = ~0ull;
 // ------------------------------------------------------------------------------------------- Poseidon
 // 12 lanes of state live in registers of ONE thread; one thread = one sponge.  (Leaf hashing has ~10^5..10^6
 // independent sponges per tree, so thread-per-sponge already fills the chip with coalesced column reads.)
-__device__ __forceinline__ void sponge_absorb_permute(u64* st) { gl::poseidon(st); }
+__device__ __forceinline__ void sponge_absorb_permute(u64* st) { glf::poseidon(st); }
 
 // Leaf digests of a column-major batch: digest[leaf] = hash_or_noop(row leaf of `cols` columns).
 // Columns >= active_cols are known-zero (never materialised).
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void k_hash_leaves(const u64* __restrict__ dat
             int c = c0 + k;
             if (c < cols) st[k] = c < active_cols ? d[(size_t)c * col_stride] : 0;
         }
-        gl::poseidon(st);
+        glf::poseidon(st);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) out[i] = st[i];
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void k_hash_fri_leaves(const u64* __restrict__
             int e = e0 + k;
             if (e < width) st[k] = v[(size_t)(e & 1) * len + leaf * arity + (e >> 1)];
         }
-        gl::poseidon(st);
+        glf::poseidon(st);
     }
     u64* out = digests + (size_t)blockIdx.y * dig_batch_stride + leaf * 4;
 #pragma unroll
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void k_merkle_level(const u64* __restrict__ ch
     for (int k = 0; k < 8; k++) st[k] = c[k];
 #pragma unroll
     for (int k = 8; k < 12; k++) st[k] = 0;
-    gl::poseidon(st);
+    glf::poseidon(st);
     u64* o = parent + (size_t)blockIdx.y * batch_stride + 4 * i;
 #pragma unroll
     for (int k = 0; k < 4; k++) o[k] = st[k];
@@ -100,7 +101,7 @@ __global__ void k_poseidon_states(u64* states, size_t n) {
     if (i >= n) return;
     u64 st[12];
     for (int k = 0; k < 12; k++) st[k] = states[12 * i + k];
-    gl::poseidon(st);
+    glf::poseidon(st);
     for (int k = 0; k < 12; k++) states[12 * i + k] = st[k];
 }
 
@@ -360,7 +361,7 @@ struct DevChallenger {
     __device__ void duplexing() {
         for (u32 i = 0; i < s.in_len; i++) s.state[i] = s.in[i];
         s.in_len = 0;
-        gl::poseidon(s.state);
+        glf::poseidon(s.state);
         for (int i = 0; i < 8; i++) s.out[i] = s.state[i];
         s.out_len = 8;
     }
@@ -456,13 +457,13 @@ __global__ void k_challenger(ChalArgs a) {
 }
 
 // Proof-of-work grinding: smallest witness w such that the duplex response has >= pow_bits leading zeros.
-// grid.x workgroups of 256 candidates each per proof (grid.y); a workgroup whose whole range lies above the
+// grid.y workgroups of 256 candidates each per proof (grid.x); a workgroup whose whole range lies above the
 // best witness found so far exits at once.
 __global__ __launch_bounds__(256) void k_pow(const ChalState* st, u64* chal, int pow_bits, unsigned long long* best /*[batch]*/) {
-    const u32 p = blockIdx.y;
-    u64 cand = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 p = blockIdx.x;  // proofs vary fastest: resident workgroups share the low candidate ranges of all proofs
+    u64 cand = (u64)blockIdx.y * blockDim.x + threadIdx.x;
     unsigned long long cur = *((volatile unsigned long long*)&best[p]);
-    if (cur < (u64)blockIdx.x * blockDim.x) return;
+    if (cur < (u64)blockIdx.y * blockDim.x) return;
     DevChallenger c;
     c.s = st[p];
     c.observe(cand);

@@ -1,0 +1,174 @@
+// Poseidon-12 for the hashing kernels: same permutation as gl::poseidon (gl.h), restructured for VALU issue slots:
+//   * lazy reduction -- state words are arbitrary u64 representatives (not < p) inside the permutation; every
+//     product is reduced once from 128 bits without the final conditional subtraction; outputs are canonicalised;
+//   * the 22 partial rounds use the sparse-matrix form derived by tools/gen_poseidon_fast.py: 23 multiply-accumulates
+//     per round instead of a 144-term MDS, with the 12-term dot product accumulated in 192 bits and reduced once.
+// Measured on MI355X (tools/microbench/int_rates.hip): v_mad_u64_u32 issues at ~2.3x the cost of a simple VALU op,
+// so the win comes from removing instructions, not from swapping multiply flavours.
+#pragma once
+#include "gl.h"
+
+namespace glf {
+using gl::u32;
+using gl::u64;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define P2F_DECL __device__ __constant__ static
+#else
+#define P2F_DECL static
+#endif
+#include "poseidon_fast.inc"
+
+GL_HD void mul128(u64 a, u64 b, u64& hi, u64& lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // 4 x (32x32 + 64 -> 64) = 4 v_mad_u64_u32; every partial sum below provably fits 64 bits
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 p00 = (u64)a0 * b0;
+    u64 mid = (u64)a0 * b1 + (p00 >> 32);
+    u64 mid2 = (u64)a1 * b0 + (u32)mid;
+    lo = (mid2 << 32) | (u32)p00;
+    hi = (u64)a1 * b1 + (mid >> 32) + (mid2 >> 32);
+#else
+    unsigned __int128 m = (unsigned __int128)a * b;
+    lo = (u64)m;
+    hi = (u64)(m >> 64);
+#endif
+}
+// hi*2^64 + lo  ->  some u64 congruent mod p (plonky2 reduce128, no canonicalisation)
+GL_HD u64 red128(u64 hi, u64 lo) {
+    u64 hh = hi >> 32, hl = hi & gl::EPS;
+    u64 t0 = lo - hh;
+    if (lo < hh) t0 -= gl::EPS;
+    u64 t1 = (hl << 32) - hl;
+    u64 r = t0 + t1;
+    if (r < t1) r += gl::EPS;
+    return r;
+}
+GL_HD u64 mulr(u64 a, u64 b) {
+    u64 hi, lo;
+    mul128(a, b, hi, lo);
+    return red128(hi, lo);
+}
+// a arbitrary u64, c canonical (< p): cannot overflow twice
+GL_HD u64 add_canon(u64 a, u64 c) {
+    u64 r = a + c;
+    if (r < a) r += gl::EPS;
+    return r;
+}
+GL_HD u64 canon(u64 a) { return a >= gl::P ? a - gl::P : a; }
+GL_HD u64 sbox7(u64 x) {
+    u64 x2 = mulr(x, x), x3 = mulr(x2, x), x4 = mulr(x2, x2);
+    return mulr(x3, x4);
+}
+// 192-bit accumulator for sums of products
+struct Acc {
+    u64 lo, hi;
+    u32 top;
+    GL_HD void init() {
+        lo = hi = 0;
+        top = 0;
+    }
+    GL_HD void fma(u64 a, u64 b) {
+        u64 ph, pl;
+        mul128(a, b, ph, pl);
+        lo += pl;
+        u64 c = lo < pl;
+        hi += c;
+        top += hi < c;
+        hi += ph;
+        top += hi < ph;
+    }
+    GL_HD void add(u64 a) {
+        lo += a;
+        u64 c = lo < a;
+        hi += c;
+        top += hi < c;
+    }
+    // 2^128 = -2^32 (mod p)
+    GL_HD u64 reduce() const {
+        u64 r = red128(hi, lo);
+        u64 t = (u64)top << 32;  // canonical (top is tiny)
+        r = canon(r);
+        return r >= t ? r - t : r + (gl::P - t);
+    }
+};
+
+GL_HD void mds_full(u64* s) {
+    const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    u64 lo[12], hi[12], out[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        lo[i] = s[i] & gl::EPS;
+        hi[i] = s[i] >> 32;
+    }
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+        u64 al = 0, ah = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            int j = (i + r) % 12;
+            al += lo[j] * C[i];
+            ah += hi[j] * C[i];
+        }
+        if (r == 0) {
+            al += lo[0] * 8;
+            ah += hi[0] * 8;
+        }
+        u64 l = al + (ah << 32);
+        u64 h = (ah >> 32) + (l < al ? 1 : 0);
+        out[r] = red128(h, l);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = out[i];
+}
+
+GL_HD void full_round(u64* s, const unsigned long long* rc) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = sbox7(add_canon(s[i], rc[i]));
+    mds_full(s);
+}
+
+// In: canonical or not; out: canonical.
+GL_HD void poseidon(u64* s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long* RC = (const unsigned long long*)gl::D_POSEIDON_RC;
+#else
+    const unsigned long long* RC = (const unsigned long long*)gl::H_POSEIDON_RC;
+#endif
+    for (int r = 0; r < 4; r++) full_round(s, RC + 12 * r);
+    {  // dense 11x11 on s[1..], once
+        u64 t[11];
+        for (int r = 0; r < 11; r++) {
+            Acc a;
+            a.init();
+#pragma unroll
+            for (int c = 0; c < 11; c++) a.fma(PF_D0[r * 11 + c], s[1 + c]);
+            t[r] = a.reduce();
+        }
+#pragma unroll
+        for (int r = 0; r < 11; r++) s[1 + r] = t[r];
+    }
+    for (int i = 0; i < 22; i++) {
+        u64 s0 = sbox7(add_canon(s[0], PF_A[i]));
+        Acc a;
+        a.init();
+        a.fma(25, s0);
+#pragma unroll
+        for (int j = 0; j < 11; j++) a.fma(PF_WHAT[i * 11 + j], s[1 + j]);
+#pragma unroll
+        for (int j = 0; j < 11; j++) {
+            u64 ph, pl;
+            mul128(PF_V[i * 11 + j], s0, ph, pl);
+            pl += s[1 + j];
+            ph += pl < s[1 + j];
+            s[1 + j] = red128(ph, pl);
+        }
+        s[0] = a.reduce();
+    }
+    full_round(s, PF_RC26);
+    for (int r = 27; r < 30; r++) full_round(s, RC + 12 * r);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = canon(s[i]);
+}
+
+}  // namespace glf

@@ -30,10 +30,32 @@ struct Tree {
     size_t stride() const { return (size_t)8 << bits; }
 };
 
+struct Workspace {
+    hipStream_t stream = nullptr;
+    u64* d_input_values = nullptr;
+    u64* d_values = nullptr;
+    u32* d_mult = nullptr;
+    int* d_status = nullptr;
+    u64 *d_wires = nullptr, *d_wcoef = nullptr, *d_wlde = nullptr;
+    u64 *d_zs = nullptr, *d_zcoef = nullptr, *d_zlde = nullptr, *d_permq = nullptr, *d_lktmp = nullptr;
+    u64 *d_qvals = nullptr, *d_qres = nullptr, *d_qcoef = nullptr, *d_qlde = nullptr;
+    Tree wtree, ztree, qtree;
+    ChalState* d_chal_state = nullptr;
+    u64* d_chal = nullptr;
+    u64 *d_pows = nullptr, *d_ev = nullptr, *d_obs = nullptr, *d_comp = nullptr;
+    u64* d_fri_coef[9] = {nullptr};  // [2][n_r]
+    u64* d_fri_vals[9] = {nullptr};  // [2][8 n_r]
+    Tree fri_tree[9];
+    unsigned long long* d_pow_best = nullptr;
+    uint8_t* d_proofs = nullptr;
+    PolyRef* d_polyrefs = nullptr;
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+};
+
 struct p2_circuit {
     Circuit c;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // setup stream (= ws[0] once workspaces exist)
     size_t n = 0, N = 0;
     u32 logn = 0, lde_bits = 0, active_wires = 0;
     size_t pbytes = 0;
@@ -54,33 +76,21 @@ struct p2_circuit {
     Tree pre_tree;
     u64* d_digest = nullptr;  // circuit digest (4)
     std::vector<u64> verifier_data;
-    PolyRef* d_polyrefs = nullptr;
     u32 n_b0 = 0, n_b1 = 0;
     u32 *d_map_obs = nullptr, *d_map_ser = nullptr;
     u32 n_obs = 0, n_ser = 0, ev_count = 0;
-    // ---- per-chunk workspace
-    size_t chunk = 0;
+    // ---- per-stream workspaces: chunks are dealt round-robin to streams so that the latency-bound stages of one
+    // chunk (witness levels, Fiat-Shamir, PoW tail) overlap with the Poseidon-heavy stages of another
+    std::vector<struct Workspace*> ws;
+    Workspace* cur = nullptr;  // workspace the host thread is currently enqueueing into (under `mu`)
+    Workspace setup_ws;        // used before any per-chunk workspace exists (preprocessing, primitives)
+    hipStream_t cur_stream() { return cur ? cur->stream : stream; }
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>>& cur_pending() { return cur ? cur->pending : setup_ws.pending; }
     u32 ws_inputs = 0;
     u32* d_input_slots = nullptr;
-    u64* d_input_values = nullptr;
-    u64* d_values = nullptr;
-    u32* d_mult = nullptr;
-    int* d_status = nullptr;
-    u64 *d_wires = nullptr, *d_wcoef = nullptr, *d_wlde = nullptr;
-    u64 *d_zs = nullptr, *d_zcoef = nullptr, *d_zlde = nullptr, *d_permq = nullptr, *d_lktmp = nullptr;
-    u64 *d_qvals = nullptr, *d_qres = nullptr, *d_qcoef = nullptr, *d_qlde = nullptr;
-    Tree wtree, ztree, qtree;
-    ChalState* d_chal_state = nullptr;
-    u64* d_chal = nullptr;
-    u64 *d_pows = nullptr, *d_ev = nullptr, *d_obs = nullptr, *d_comp = nullptr;
-    u64* d_fri_coef[9] = {nullptr};  // [2][n_r]
-    u64* d_fri_vals[9] = {nullptr};  // [2][8 n_r]
-    Tree fri_tree[9];
-    unsigned long long* d_pow_best = nullptr;
-    uint8_t* d_proofs = nullptr;
+    size_t chunk = 0;
     // timing
     bool timing_on = false;
-    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
     std::map<std::string, std::pair<float, u32>> times;
     std::vector<void*> allocs;
     std::mutex mu;
@@ -106,14 +116,14 @@ static int upload(p2_circuit* C, T** p, const T* host, size_t count) {
     do {                                                                                              \
         hipEvent_t _e0 = nullptr, _e1 = nullptr;                                                      \
         if ((C)->timing_on) {                                                                         \
-            hipEventCreate(&_e0);                                                                     \
-            hipEventCreate(&_e1);                                                                     \
-            hipEventRecord(_e0, (C)->stream);                                                         \
+            (void)hipEventCreate(&_e0);                                                                     \
+            (void)hipEventCreate(&_e1);                                                                     \
+            (void)hipEventRecord(_e0, (C)->cur_stream());                                                         \
         }                                                                                             \
-        hipLaunchKernelGGL(kernel, grid, block, shmem, (C)->stream, __VA_ARGS__);                     \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (C)->cur_stream(), __VA_ARGS__);                     \
         if ((C)->timing_on) {                                                                         \
-            hipEventRecord(_e1, (C)->stream);                                                         \
-            (C)->pending.push_back({name, {_e0, _e1}});                                               \
+            (void)hipEventRecord(_e1, (C)->cur_stream());                                                         \
+            (C)->cur_pending().push_back({name, {_e0, _e1}});                                               \
         }                                                                                             \
         HIPCHECK(hipGetLastError());                                                                  \
     } while (0)
@@ -178,8 +188,8 @@ static size_t cap_off(const Tree& t, u32 cap_height) {
 }
 static int challenger(p2_circuit* C, u32 stage, const u64* observe, size_t stride, u32 len, u32 aux, u64 mod, u32 batch) {
     ChalArgs a{};
-    a.st = C->d_chal_state;
-    a.chal = C->d_chal;
+    a.st = C->cur->d_chal_state;
+    a.chal = C->cur->d_chal;
     a.observe = observe;
     a.observe_stride = stride;
     a.observe_len = len;
@@ -188,7 +198,7 @@ static int challenger(p2_circuit* C, u32 stage, const u64* observe, size_t strid
     a.aux = aux;
     a.mod = mod;
     a.digest = C->d_digest;
-    a.status = C->d_status;
+    a.status = C->cur->d_status;
     LAUNCH(C, "challenger", k_challenger, g1(batch, 64), dim3(64), 0, a);
     return 0;
 }
@@ -347,55 +357,64 @@ static int circuit_setup(p2_circuit* C) {
     return 0;
 }
 
-static int alloc_workspace(p2_circuit* C, size_t chunk, u32 n_inputs) {
+static int setup_polyrefs(p2_circuit* C);
+static int alloc_workspace(p2_circuit* C, size_t chunk, u32 n_inputs, size_t nstreams) {
     const Circuit& c = C->c;
     const size_t n = C->n, N = C->N;
     const u32 zc = c.num_zs_cols(), qc = c.num_quotient_cols(), NC = c.cfg.num_challenges, act = C->active_wires;
-    if (C->chunk >= chunk && C->ws_inputs >= n_inputs) return 0;
+    if (C->chunk >= chunk && C->ws_inputs >= n_inputs && C->ws.size() >= nstreams) return 0;
     if (C->chunk != 0) return set_error("workspace already allocated with a smaller shape; create a new p2_circuit"), P2_ERR_INVALID;
     C->chunk = chunk;
     C->ws_inputs = std::max<u32>(n_inputs, 1);
     int e = 0;
     e |= dalloc(C, &C->d_input_slots, C->ws_inputs);
-    e |= dalloc(C, &C->d_input_values, chunk * C->ws_inputs);
-    e |= dalloc(C, &C->d_values, chunk * c.num_slots);
-    e |= dalloc(C, &C->d_mult, chunk * std::max<size_t>(C->total_lut_entries, 1));
-    e |= dalloc(C, &C->d_status, chunk);
-    e |= dalloc(C, &C->d_wires, chunk * act * n);
-    e |= dalloc(C, &C->d_wcoef, chunk * act * n);
-    e |= dalloc(C, &C->d_wlde, chunk * act * N);
-    e |= dalloc(C, &C->d_zs, chunk * zc * n);
-    e |= dalloc(C, &C->d_zcoef, chunk * zc * n);
-    e |= dalloc(C, &C->d_zlde, chunk * zc * N);
-    e |= dalloc(C, &C->d_permq, chunk * NC * (c.num_partial_products() + 1) * n);
-    e |= dalloc(C, &C->d_lktmp, chunk * NC * (c.num_sldc_polys() + 1) * n);
-    e |= dalloc(C, &C->d_qvals, chunk * NC * N);
-    e |= dalloc(C, &C->d_qres, chunk * NC * N);
-    e |= dalloc(C, &C->d_qcoef, chunk * qc * n);
-    e |= dalloc(C, &C->d_qlde, chunk * qc * N);
-    for (Tree* t : {&C->wtree, &C->ztree, &C->qtree}) {
+    for (size_t wi = 0; wi < nstreams && !e; wi++) {
+    Workspace* W = new Workspace();
+    C->ws.push_back(W);
+    C->cur = W;
+    if (hipStreamCreateWithFlags(&W->stream, hipStreamNonBlocking) != hipSuccess) return set_error("hipStreamCreate failed"), P2_ERR_HIP;
+    e |= dalloc(C, &C->cur->d_input_values, chunk * C->ws_inputs);
+    e |= dalloc(C, &C->cur->d_values, chunk * c.num_slots);
+    e |= dalloc(C, &C->cur->d_mult, chunk * std::max<size_t>(C->total_lut_entries, 1));
+    e |= dalloc(C, &C->cur->d_status, chunk);
+    e |= dalloc(C, &C->cur->d_wires, chunk * act * n);
+    e |= dalloc(C, &C->cur->d_wcoef, chunk * act * n);
+    e |= dalloc(C, &C->cur->d_wlde, chunk * act * N);
+    e |= dalloc(C, &C->cur->d_zs, chunk * zc * n);
+    e |= dalloc(C, &C->cur->d_zcoef, chunk * zc * n);
+    e |= dalloc(C, &C->cur->d_zlde, chunk * zc * N);
+    e |= dalloc(C, &C->cur->d_permq, chunk * NC * (c.num_partial_products() + 1) * n);
+    e |= dalloc(C, &C->cur->d_lktmp, chunk * NC * (c.num_sldc_polys() + 1) * n);
+    e |= dalloc(C, &C->cur->d_qvals, chunk * NC * N);
+    e |= dalloc(C, &C->cur->d_qres, chunk * NC * N);
+    e |= dalloc(C, &C->cur->d_qcoef, chunk * qc * n);
+    e |= dalloc(C, &C->cur->d_qlde, chunk * qc * N);
+    for (Tree* t : {&C->cur->wtree, &C->cur->ztree, &C->cur->qtree}) {
         t->bits = C->lde_bits;
         e |= dalloc(C, &t->dig, chunk * t->stride());
     }
-    e |= dalloc(C, &C->d_chal_state, chunk);
-    e |= dalloc(C, &C->d_chal, chunk * CH_WORDS);
-    e |= dalloc(C, &C->d_pows, chunk * 8 * n);
-    e |= dalloc(C, &C->d_ev, chunk * 2 * C->ev_count);
-    e |= dalloc(C, &C->d_obs, chunk * 2 * C->n_obs);
-    e |= dalloc(C, &C->d_comp, chunk * 4 * n);
+    e |= dalloc(C, &C->cur->d_chal_state, chunk);
+    e |= dalloc(C, &C->cur->d_chal, chunk * CH_WORDS);
+    e |= dalloc(C, &C->cur->d_pows, chunk * 8 * n);
+    e |= dalloc(C, &C->cur->d_ev, chunk * 2 * C->ev_count);
+    e |= dalloc(C, &C->cur->d_obs, chunk * 2 * C->n_obs);
+    e |= dalloc(C, &C->cur->d_comp, chunk * 4 * n);
     u32 logn_r = C->logn;
     for (u32 r = 0; r <= C->arities.size(); r++) {
         size_t n_r = (size_t)1 << logn_r;
-        e |= dalloc(C, &C->d_fri_coef[r], chunk * 2 * n_r);
+        e |= dalloc(C, &C->cur->d_fri_coef[r], chunk * 2 * n_r);
         if (r < C->arities.size()) {
-            e |= dalloc(C, &C->d_fri_vals[r], chunk * 2 * 8 * n_r);
-            C->fri_tree[r].bits = logn_r + c.cfg.rate_bits - C->arities[r];
-            e |= dalloc(C, &C->fri_tree[r].dig, chunk * C->fri_tree[r].stride());
+            e |= dalloc(C, &C->cur->d_fri_vals[r], chunk * 2 * 8 * n_r);
+            C->cur->fri_tree[r].bits = logn_r + c.cfg.rate_bits - C->arities[r];
+            e |= dalloc(C, &C->cur->fri_tree[r].dig, chunk * C->cur->fri_tree[r].stride());
             logn_r -= C->arities[r];
         }
     }
-    e |= dalloc(C, &C->d_pow_best, chunk);
-    e |= dalloc(C, &C->d_proofs, chunk * C->pbytes);
+    e |= dalloc(C, &C->cur->d_pow_best, chunk);
+    e |= dalloc(C, &C->cur->d_proofs, chunk * C->pbytes);
+    e |= setup_polyrefs(C);
+    }
+    C->cur = nullptr;
     return e ? P2_ERR_HIP : 0;
 }
 
@@ -408,9 +427,9 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
     const u32 zc = c.num_zs_cols(), qc = c.num_quotient_cols(), act = C->active_wires, ncc = c.num_constants_cols(), np = c.num_preprocessed();
     const u32 cap_h = c.cfg.cap_height, cap_words = 4u << cap_h, nsldc = c.num_sldc_polys();
     const size_t ws = (size_t)act * n, wls = (size_t)act * N, zs_s = (size_t)zc * n, zl_s = (size_t)zc * N;
-    hipStream_t st = C->stream;
+    hipStream_t st = C->cur_stream();
     // 1. witness
-    HIPCHECK(hipMemsetAsync(C->d_mult, 0, (size_t)B * std::max<size_t>(C->total_lut_entries, 1) * 4, st));
+    HIPCHECK(hipMemsetAsync(C->cur->d_mult, 0, (size_t)B * std::max<size_t>(C->total_lut_entries, 1) * 4, st));
     {
         WitnessArgs a{};
         a.ops = C->d_ops;
@@ -420,51 +439,51 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         a.n_inputs = n_inputs;
         a.input_slots = C->d_input_slots;
         a.input_values = d_values;
-        a.values = C->d_values;
+        a.values = C->cur->d_values;
         a.lut_idx = C->d_lut_idx;
         a.lut_pairs = C->d_lut_pairs;
         a.lut_offsets = C->d_lut_offsets;
-        a.mult = C->d_mult;
+        a.mult = C->cur->d_mult;
         a.total_lut_entries = C->total_lut_entries;
-        a.status = C->d_status;
+        a.status = C->cur->d_status;
         LAUNCH(C, "witness", k_witness, dim3(B), dim3(1024), 0, a);
     }
-    LAUNCH(C, "fill_wires", k_fill_wires, g1((size_t)R * n, 256, B), dim3(256), 0, C->d_wire_slot, C->d_values, C->d_wires, (size_t)R * n, c.num_slots, ws,
-           C->d_status);
+    LAUNCH(C, "fill_wires", k_fill_wires, g1((size_t)R * n, 256, B), dim3(256), 0, C->d_wire_slot, C->cur->d_values, C->cur->d_wires, (size_t)R * n, c.num_slots, ws,
+           C->cur->d_status);
     if (!c.luts.empty()) {
         LutRowsArgs a{};
         a.lut_pairs = C->d_lut_pairs;
         a.lut_offsets = C->d_lut_offsets;
         a.rows = C->d_lookup_rows;
         a.num_lookups = C->d_num_lookups;
-        a.mult = C->d_mult;
+        a.mult = C->cur->d_mult;
         a.total_lut_entries = C->total_lut_entries;
-        a.wires = C->d_wires;
+        a.wires = C->cur->d_wires;
         a.wires_batch_stride = ws;
         a.n = (u32)n;
         a.num_luts = (u32)c.luts.size();
         LAUNCH(C, "lut_rows", k_lut_rows, g1(std::max<size_t>(C->total_lut_entries, 256), 256, B), dim3(256), 0, a);
     }
     // 2. wires commitment
-    if (intt_cols(C, C->d_wires, C->d_wcoef, act, ws, B)) return P2_ERR_HIP;
-    if (lde_cols(C, C->d_wcoef, ws, C->d_wlde, wls, act, 0, B)) return P2_ERR_HIP;
-    if (merkle_build(C, C->d_wlde, c.cfg.num_wires, act, N, wls, C->wtree, B)) return P2_ERR_HIP;
+    if (intt_cols(C, C->cur->d_wires, C->cur->d_wcoef, act, ws, B)) return P2_ERR_HIP;
+    if (lde_cols(C, C->cur->d_wcoef, ws, C->cur->d_wlde, wls, act, 0, B)) return P2_ERR_HIP;
+    if (merkle_build(C, C->cur->d_wlde, c.cfg.num_wires, act, N, wls, C->cur->wtree, B)) return P2_ERR_HIP;
     // 3. betas, gammas, deltas
-    if (challenger(C, 0, C->wtree.dig + cap_off(C->wtree, cap_h), C->wtree.stride(), cap_words, nlp ? 1 : 0, 0, B)) return P2_ERR_HIP;
+    if (challenger(C, 0, C->cur->wtree.dig + cap_off(C->cur->wtree, cap_h), C->cur->wtree.stride(), cap_words, nlp ? 1 : 0, 0, B)) return P2_ERR_HIP;
     // 4. partial products and Z
-    HIPCHECK(hipMemsetAsync(C->d_zs, 0, (size_t)B * zs_s * 8, st));
-    LAUNCH(C, "perm_chunks", k_perm_chunks, g1(n, 256, B, NC * (npp + 1)), dim3(256), 0, C->d_wires, ws, C->d_sigmas, C->d_k_is, C->d_subgroup, C->d_chal,
-           C->d_permq, (size_t)NC * (npp + 1) * n, (u32)n, R, c.cfg.quotient_degree_factor, npp + 1);
-    LAUNCH(C, "perm_scan", k_perm_scan, dim3(NC, B), dim3(1024), 0, C->d_permq, (size_t)NC * (npp + 1) * n, C->d_zs, zs_s, (u32)n, npp + 1, NC);
+    HIPCHECK(hipMemsetAsync(C->cur->d_zs, 0, (size_t)B * zs_s * 8, st));
+    LAUNCH(C, "perm_chunks", k_perm_chunks, g1(n, 256, B, NC * (npp + 1)), dim3(256), 0, C->cur->d_wires, ws, C->d_sigmas, C->d_k_is, C->d_subgroup, C->cur->d_chal,
+           C->cur->d_permq, (size_t)NC * (npp + 1) * n, (u32)n, R, c.cfg.quotient_degree_factor, npp + 1);
+    LAUNCH(C, "perm_scan", k_perm_scan, dim3(NC, B), dim3(1024), 0, C->cur->d_permq, (size_t)NC * (npp + 1) * n, C->cur->d_zs, zs_s, (u32)n, npp + 1, NC);
     // 5. lookup polynomials
     if (nlp) {
         LookupArgs a{};
-        a.wires = C->d_wires;
+        a.wires = C->cur->d_wires;
         a.wires_batch_stride = ws;
-        a.chal = C->d_chal;
-        a.zs = C->d_zs;
+        a.chal = C->cur->d_chal;
+        a.zs = C->cur->d_zs;
         a.zs_batch_stride = zs_s;
-        a.tmp = C->d_lktmp;
+        a.tmp = C->cur->d_lktmp;
         a.tmp_batch_stride = (size_t)NC * (nsldc + 1) * n;
         a.rows = C->d_lookup_rows;
         a.n = (u32)n;
@@ -478,24 +497,24 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         LAUNCH(C, "lookup_scan", k_lookup_scan, dim3((u32)c.luts.size(), B, NC), dim3(1024), 0, a);
     }
     // 6. zs commitment, alphas
-    if (intt_cols(C, C->d_zs, C->d_zcoef, zc, zs_s, B)) return P2_ERR_HIP;
-    if (lde_cols(C, C->d_zcoef, zs_s, C->d_zlde, zl_s, zc, 0, B)) return P2_ERR_HIP;
-    if (merkle_build(C, C->d_zlde, zc, zc, N, zl_s, C->ztree, B)) return P2_ERR_HIP;
-    if (challenger(C, 1, C->ztree.dig + cap_off(C->ztree, cap_h), C->ztree.stride(), cap_words, 0, 0, B)) return P2_ERR_HIP;
+    if (intt_cols(C, C->cur->d_zs, C->cur->d_zcoef, zc, zs_s, B)) return P2_ERR_HIP;
+    if (lde_cols(C, C->cur->d_zcoef, zs_s, C->cur->d_zlde, zl_s, zc, 0, B)) return P2_ERR_HIP;
+    if (merkle_build(C, C->cur->d_zlde, zc, zc, N, zl_s, C->cur->ztree, B)) return P2_ERR_HIP;
+    if (challenger(C, 1, C->cur->ztree.dig + cap_off(C->cur->ztree, cap_h), C->cur->ztree.stride(), cap_words, 0, 0, B)) return P2_ERR_HIP;
     // 7. quotient
     {
         QuotientArgs a{};
         a.pre_lde = C->d_pre_lde;
-        a.wires_lde = C->d_wlde;
-        a.zs_lde = C->d_zlde;
+        a.wires_lde = C->cur->d_wlde;
+        a.zs_lde = C->cur->d_zlde;
         a.wires_batch_stride = wls;
         a.zs_batch_stride = zl_s;
-        a.chal = C->d_chal;
+        a.chal = C->cur->d_chal;
         a.xs = C->d_xs;
         a.l0 = C->d_l0;
         a.zh_inv = C->d_zh_inv;
         a.k_is = C->d_k_is;
-        a.out = C->d_qvals;
+        a.out = C->cur->d_qvals;
         a.out_batch_stride = (size_t)NC * N;
         a.n = (u32)n;
         a.logn = C->logn;
@@ -520,13 +539,13 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
             a.group_hi[g] = c.groups[c.selector_index[g]].second;
         }
         for (u32 l = 0; l < c.luts.size(); l++) a.lut_last_row[l] = c.lookup_rows[l].last_lut;
-        a.zs_values = C->d_zs;
+        a.zs_values = C->cur->d_zs;
         a.zs_values_batch_stride = zs_s;
         LAUNCH(C, "quotient", k_quotient, g1(N, 256, B), dim3(256), 0, a);
         // coset-wise inverse transform: residues r_j, then the 8-point cross-coset DFT
         NttArgs t{};
-        t.in = C->d_qvals;
-        t.out = C->d_qres;
+        t.in = C->cur->d_qvals;
+        t.out = C->cur->d_qres;
         t.tw = C->d_tw_inv;
         t.post = C->d_shift_inv_pows;
         t.post_scalar = 1;
@@ -541,41 +560,41 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         for (u32 j = 0; j < 8; j++) t.block_of_coset[j] = gl::bitrev(j, 3);
         // (output uses the same block index; k_quotient_chunks reads block rev3(j) as coset j)
         if (run_ntt(C, "quotient_intt", t, NC, B)) return P2_ERR_HIP;
-        LAUNCH(C, "quotient_chunks", k_quotient_chunks_rev, g1(n, 256, B, NC), dim3(256), 0, C->d_qres, C->d_qcoef, (u32)n, (size_t)NC * N, (size_t)qc * n,
+        LAUNCH(C, "quotient_chunks", k_quotient_chunks_rev, g1(n, 256, B, NC), dim3(256), 0, C->cur->d_qres, C->cur->d_qcoef, (u32)n, (size_t)NC * N, (size_t)qc * n,
                C->d_w8inv, C->d_qscale);
     }
-    if (lde_cols(C, C->d_qcoef, (size_t)qc * n, C->d_qlde, (size_t)qc * N, qc, 0, B)) return P2_ERR_HIP;
-    if (merkle_build(C, C->d_qlde, qc, qc, N, (size_t)qc * N, C->qtree, B)) return P2_ERR_HIP;
-    if (challenger(C, 2, C->qtree.dig + cap_off(C->qtree, cap_h), C->qtree.stride(), cap_words, c.degree_bits, 0, B)) return P2_ERR_HIP;
+    if (lde_cols(C, C->cur->d_qcoef, (size_t)qc * n, C->cur->d_qlde, (size_t)qc * N, qc, 0, B)) return P2_ERR_HIP;
+    if (merkle_build(C, C->cur->d_qlde, qc, qc, N, (size_t)qc * N, C->cur->qtree, B)) return P2_ERR_HIP;
+    if (challenger(C, 2, C->cur->qtree.dig + cap_off(C->cur->qtree, cap_h), C->cur->qtree.stride(), cap_words, c.degree_bits, 0, B)) return P2_ERR_HIP;
     // 8. openings
-    LAUNCH(C, "zeta_pows", k_zeta_pows, g1(n, 256, B, 4), dim3(256), 0, C->d_chal, C->d_pows, (size_t)8 * n, (u32)n, gl::root_of_unity((int)C->logn));
-    HIPCHECK(hipMemsetAsync(C->d_ev, 0, (size_t)B * 2 * C->ev_count * 8, st));
+    LAUNCH(C, "zeta_pows", k_zeta_pows, g1(n, 256, B, 4), dim3(256), 0, C->cur->d_chal, C->cur->d_pows, (size_t)8 * n, (u32)n, gl::root_of_unity((int)C->logn));
+    HIPCHECK(hipMemsetAsync(C->cur->d_ev, 0, (size_t)B * 2 * C->ev_count * 8, st));
     {
         const size_t evs = 2 * (size_t)C->ev_count;
-        u64* ev = C->d_ev;
-        LAUNCH(C, "eval_polys", k_eval_polys, dim3(np, B), dim3(256), 0, C->d_pre_coeffs, (size_t)0, C->d_pows, (size_t)8 * n, (u32)n, ev, evs);
-        LAUNCH(C, "eval_polys", k_eval_polys, dim3(act, B), dim3(256), 0, C->d_wcoef, ws, C->d_pows, (size_t)8 * n, (u32)n, ev + 2 * (size_t)np, evs);
-        LAUNCH(C, "eval_polys", k_eval_polys, dim3(zc, B), dim3(256), 0, C->d_zcoef, zs_s, C->d_pows, (size_t)8 * n, (u32)n, ev + 2 * (size_t)(np + c.cfg.num_wires), evs);
-        LAUNCH(C, "eval_polys", k_eval_polys, dim3(zc, B), dim3(256), 0, C->d_zcoef, zs_s, C->d_pows + 2 * n, (size_t)8 * n, (u32)n,
+        u64* ev = C->cur->d_ev;
+        LAUNCH(C, "eval_polys", k_eval_polys, dim3(np, B), dim3(256), 0, C->d_pre_coeffs, (size_t)0, C->cur->d_pows, (size_t)8 * n, (u32)n, ev, evs);
+        LAUNCH(C, "eval_polys", k_eval_polys, dim3(act, B), dim3(256), 0, C->cur->d_wcoef, ws, C->cur->d_pows, (size_t)8 * n, (u32)n, ev + 2 * (size_t)np, evs);
+        LAUNCH(C, "eval_polys", k_eval_polys, dim3(zc, B), dim3(256), 0, C->cur->d_zcoef, zs_s, C->cur->d_pows, (size_t)8 * n, (u32)n, ev + 2 * (size_t)(np + c.cfg.num_wires), evs);
+        LAUNCH(C, "eval_polys", k_eval_polys, dim3(zc, B), dim3(256), 0, C->cur->d_zcoef, zs_s, C->cur->d_pows + 2 * n, (size_t)8 * n, (u32)n,
                ev + 2 * (size_t)(np + c.cfg.num_wires + zc), evs);
-        LAUNCH(C, "eval_polys", k_eval_polys, dim3(qc, B), dim3(256), 0, C->d_qcoef, (size_t)qc * n, C->d_pows, (size_t)8 * n, (u32)n,
+        LAUNCH(C, "eval_polys", k_eval_polys, dim3(qc, B), dim3(256), 0, C->cur->d_qcoef, (size_t)qc * n, C->cur->d_pows, (size_t)8 * n, (u32)n,
                ev + 2 * (size_t)(np + c.cfg.num_wires + 2 * zc), evs);
-        LAUNCH(C, "gather_ext", k_gather_ext, g1(C->n_obs, 256, B), dim3(256), 0, C->d_ev, evs, C->d_map_obs, C->n_obs, C->d_obs, (size_t)2 * C->n_obs);
+        LAUNCH(C, "gather_ext", k_gather_ext, g1(C->n_obs, 256, B), dim3(256), 0, C->cur->d_ev, evs, C->d_map_obs, C->n_obs, C->cur->d_obs, (size_t)2 * C->n_obs);
     }
-    if (challenger(C, 3, C->d_obs, (size_t)2 * C->n_obs, 2 * C->n_obs, 0, 0, B)) return P2_ERR_HIP;
+    if (challenger(C, 3, C->cur->d_obs, (size_t)2 * C->n_obs, 2 * C->n_obs, 0, 0, B)) return P2_ERR_HIP;
     // 9. FRI: compose, divide, commit phase
-    LAUNCH(C, "fri_compose", k_fri_compose, g1(n, 256, B), dim3(256), 0, C->d_polyrefs, C->n_b0, C->n_b1, C->d_chal, (u32)n, C->d_comp, (size_t)4 * n);
-    LAUNCH(C, "fri_divide", k_fri_divide, dim3(B), dim3(1024), 0, C->d_comp, (size_t)4 * n, C->d_pows, (size_t)8 * n, C->d_chal, (u32)n, C->n_b1, C->d_fri_coef[0],
+    LAUNCH(C, "fri_compose", k_fri_compose, g1(n, 256, B), dim3(256), 0, C->cur->d_polyrefs, C->n_b0, C->n_b1, C->cur->d_chal, (u32)n, C->cur->d_comp, (size_t)4 * n);
+    LAUNCH(C, "fri_divide", k_fri_divide, dim3(B), dim3(1024), 0, C->cur->d_comp, (size_t)4 * n, C->cur->d_pows, (size_t)8 * n, C->cur->d_chal, (u32)n, C->n_b1, C->cur->d_fri_coef[0],
            (size_t)2 * n);
     {
         u32 logn_r = C->logn;
         for (u32 r = 0; r < C->arities.size(); r++) {
             size_t n_r = (size_t)1 << logn_r, len = 8 * n_r;
             u32 arity = 1u << C->arities[r];
-            if (lde_cols(C, C->d_fri_coef[r], 2 * n_r, C->d_fri_vals[r], 2 * len, 2, r, B)) return P2_ERR_HIP;
-            Tree& t = C->fri_tree[r];
+            if (lde_cols(C, C->cur->d_fri_coef[r], 2 * n_r, C->cur->d_fri_vals[r], 2 * len, 2, r, B)) return P2_ERR_HIP;
+            Tree& t = C->cur->fri_tree[r];
             size_t leaves = len / arity;
-            LAUNCH(C, "hash_fri_leaves", k_hash_fri_leaves, g1(leaves, 256, B), dim3(256), 0, C->d_fri_vals[r], len, 2 * len, (int)arity, t.dig, t.stride());
+            LAUNCH(C, "hash_fri_leaves", k_hash_fri_leaves, g1(leaves, 256, B), dim3(256), 0, C->cur->d_fri_vals[r], len, 2 * len, (int)arity, t.dig, t.stride());
             for (u32 l = 0; l + cap_h < t.bits; l++) {
                 size_t parents = leaves >> (l + 1);
                 size_t off_c = 4 * (((size_t)2 << t.bits) - ((size_t)2 << (t.bits - l)));
@@ -584,38 +603,38 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
             }
             if (challenger(C, 4, t.dig + cap_off(t, cap_h), t.stride(), cap_words, r, 0, B)) return P2_ERR_HIP;
             size_t n_next = n_r >> C->arities[r];
-            LAUNCH(C, "fri_fold", k_fri_fold, g1(n_next, 256, B), dim3(256), 0, C->d_fri_coef[r], n_r, 2 * n_r, C->d_fri_coef[r + 1], n_next, 2 * n_next, C->d_chal, r,
+            LAUNCH(C, "fri_fold", k_fri_fold, g1(n_next, 256, B), dim3(256), 0, C->cur->d_fri_coef[r], n_r, 2 * n_r, C->cur->d_fri_coef[r + 1], n_next, 2 * n_next, C->cur->d_chal, r,
                    arity);
             logn_r -= C->arities[r];
         }
         // final polynomial (interleave components for observation)
         size_t fl = (size_t)1 << logn_r;
         u32 R_ = (u32)C->arities.size();
-        LAUNCH(C, "interleave", k_interleave_ext, g1(fl, 256, B), dim3(256), 0, C->d_fri_coef[R_], fl, 2 * fl, C->d_obs, (size_t)2 * C->n_obs);
-        if (challenger(C, 5, C->d_obs, (size_t)2 * C->n_obs, (u32)(2 * fl), 0, 0, B)) return P2_ERR_HIP;
+        LAUNCH(C, "interleave", k_interleave_ext, g1(fl, 256, B), dim3(256), 0, C->cur->d_fri_coef[R_], fl, 2 * fl, C->cur->d_obs, (size_t)2 * C->n_obs);
+        if (challenger(C, 5, C->cur->d_obs, (size_t)2 * C->n_obs, (u32)(2 * fl), 0, 0, B)) return P2_ERR_HIP;
         // proof of work
-        HIPCHECK(hipMemsetAsync(C->d_pow_best, 0xFF, (size_t)B * 8, st));
-        LAUNCH(C, "pow", k_pow, dim3(1u << 14, B), dim3(256), 0, C->d_chal_state, C->d_chal, (int)c.cfg.pow_bits, C->d_pow_best);
-        LAUNCH(C, "pow_finish", k_pow_finish, g1(B, 64), dim3(64), 0, C->d_chal, C->d_pow_best, B, C->d_status);
-        if (challenger(C, 6, C->d_obs, 0, 0, c.cfg.num_query_rounds, (u64)N, B)) return P2_ERR_HIP;
+        HIPCHECK(hipMemsetAsync(C->cur->d_pow_best, 0xFF, (size_t)B * 8, st));
+        LAUNCH(C, "pow", k_pow, dim3(B, 1u << 14), dim3(256), 0, C->cur->d_chal_state, C->cur->d_chal, (int)c.cfg.pow_bits, C->cur->d_pow_best);
+        LAUNCH(C, "pow_finish", k_pow_finish, g1(B, 64), dim3(64), 0, C->cur->d_chal, C->cur->d_pow_best, B, C->cur->d_status);
+        if (challenger(C, 6, C->cur->d_obs, 0, 0, c.cfg.num_query_rounds, (u64)N, B)) return P2_ERR_HIP;
         // 10. proof assembly
         size_t off = 0;
         const size_t pb = C->pbytes;
-        for (Tree* t : {&C->wtree, &C->ztree, &C->qtree}) {
+        for (Tree* t : {&C->cur->wtree, &C->cur->ztree, &C->cur->qtree}) {
             LAUNCH(C, "proof_copy", k_proof_copy, g1(cap_words, 64, B), dim3(64), 0, t->dig + cap_off(*t, cap_h), t->stride(), cap_words, d_proofs, pb, off);
             off += 8 * (size_t)cap_words;
         }
-        LAUNCH(C, "proof_gather", k_proof_gather_ext, g1(C->n_ser, 256, B), dim3(256), 0, C->d_ev, 2 * (size_t)C->ev_count, C->d_map_ser, C->n_ser, d_proofs, pb, off);
+        LAUNCH(C, "proof_gather", k_proof_gather_ext, g1(C->n_ser, 256, B), dim3(256), 0, C->cur->d_ev, 2 * (size_t)C->ev_count, C->d_map_ser, C->n_ser, d_proofs, pb, off);
         off += 16 * (size_t)C->n_ser;
         for (u32 r = 0; r < R_; r++) {
-            Tree& t = C->fri_tree[r];
+            Tree& t = C->cur->fri_tree[r];
             LAUNCH(C, "proof_copy", k_proof_copy, g1(cap_words, 64, B), dim3(64), 0, t.dig + cap_off(t, cap_h), t.stride(), cap_words, d_proofs, pb, off);
             off += 8 * (size_t)cap_words;
         }
         QueryArgs q{};
-        const u64* ldes[4] = {C->d_pre_lde, C->d_wlde, C->d_zlde, C->d_qlde};
+        const u64* ldes[4] = {C->d_pre_lde, C->cur->d_wlde, C->cur->d_zlde, C->cur->d_qlde};
         const size_t lstr[4] = {0, wls, zl_s, (size_t)qc * N};
-        const Tree* trees[4] = {&C->pre_tree, &C->wtree, &C->ztree, &C->qtree};
+        const Tree* trees[4] = {&C->pre_tree, &C->cur->wtree, &C->cur->ztree, &C->cur->qtree};
         const u32 colsv[4] = {np, c.cfg.num_wires, zc, qc};
         const u32 actv[4] = {np, act, zc, qc};
         size_t qbytes = 0;
@@ -635,33 +654,39 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         u32 lb = C->lde_bits;
         for (u32 r = 0; r < R_; r++) {
             q.arity_bits[r] = C->arities[r];
-            q.fri_vals[r] = C->d_fri_vals[r];
+            q.fri_vals[r] = C->cur->d_fri_vals[r];
             q.fri_vals_batch_stride[r] = (size_t)2 << lb;
             q.fri_bits[r] = lb;
-            q.fri_digests[r] = C->fri_tree[r].dig;
-            q.fri_dig_batch_stride[r] = C->fri_tree[r].stride();
+            q.fri_digests[r] = C->cur->fri_tree[r].dig;
+            q.fri_dig_batch_stride[r] = C->cur->fri_tree[r].stride();
             qbytes += 16 * ((size_t)1 << C->arities[r]) + 1 + 32 * (size_t)(lb - C->arities[r] - cap_h);
             lb -= C->arities[r];
         }
-        q.chal = C->d_chal;
+        q.chal = C->cur->d_chal;
         q.proofs = d_proofs;
         q.proof_bytes = pb;
         q.queries_off = off;
         q.query_bytes = qbytes;
         LAUNCH(C, "write_queries", k_write_queries, dim3(c.cfg.num_query_rounds, B), dim3(256), 0, q);
         off += qbytes * c.cfg.num_query_rounds;
-        LAUNCH(C, "proof_copy_ext", k_proof_copy_ext, g1(fl, 64, B), dim3(64), 0, C->d_fri_coef[R_], 2 * fl, fl, (u32)fl, d_proofs, pb, off);
+        LAUNCH(C, "proof_copy_ext", k_proof_copy_ext, g1(fl, 64, B), dim3(64), 0, C->cur->d_fri_coef[R_], 2 * fl, fl, (u32)fl, d_proofs, pb, off);
         off += 16 * fl;
-        LAUNCH(C, "proof_copy", k_proof_copy, g1(1, 64, B), dim3(64), 0, C->d_chal + CH_POW, (size_t)CH_WORDS, 1u, d_proofs, pb, off);
+        LAUNCH(C, "proof_copy", k_proof_copy, g1(1, 64, B), dim3(64), 0, C->cur->d_chal + CH_POW, (size_t)CH_WORDS, 1u, d_proofs, pb, off);
         off += 8;
         if (off != pb) return set_error("internal: proof layout size mismatch"), P2_ERR_INVALID;
     }
-    LAUNCH(C, "finish", k_finish, g1(C->pbytes, 256, B), dim3(256), 0, C->d_status, d_status_out, d_proofs, C->pbytes, B);
+    LAUNCH(C, "finish", k_finish, g1(C->pbytes, 256, B), dim3(256), 0, C->cur->d_status, d_status_out, d_proofs, C->pbytes, B);
     return 0;
 }
 
 static void collect_timing(p2_circuit* C) {
-    for (auto& pe : C->pending) {
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> all;
+    all.swap(C->setup_ws.pending);
+    for (Workspace* W : C->ws) {
+        all.insert(all.end(), W->pending.begin(), W->pending.end());
+        W->pending.clear();
+    }
+    for (auto& pe : all) {
         float ms = 0;
         hipEventSynchronize(pe.second.second);
         hipEventElapsedTime(&ms, pe.second.first, pe.second.second);
@@ -671,7 +696,6 @@ static void collect_timing(p2_circuit* C) {
         hipEventDestroy(pe.second.first);
         hipEventDestroy(pe.second.second);
     }
-    C->pending.clear();
 }
 
 extern "C" {
@@ -756,8 +780,12 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
 void p2_circuit_free(p2_circuit* C) {
     if (!C) return;
     hipSetDevice(C->device);
-    if (C->stream) hipStreamSynchronize(C->stream);
+    hipDeviceSynchronize();
     for (void* p : C->allocs) hipFree(p);
+    for (Workspace* W : C->ws) {
+        if (W->stream) hipStreamDestroy(W->stream);
+        delete W;
+    }
     if (C->stream) hipStreamDestroy(C->stream);
     delete C;
 }
@@ -771,21 +799,20 @@ int p2_circuit_verifier_data(const p2_circuit* C, uint64_t* out, size_t cap, siz
 size_t p2_circuit_proof_bytes(const p2_circuit* C) { return C->pbytes; }
 
 static int setup_polyrefs(p2_circuit* C) {
-    if (C->d_polyrefs) return 0;
     const Circuit& c = C->c;
     const u32 np = c.num_preprocessed(), W = c.cfg.num_wires, zc = c.num_zs_cols(), qc = c.num_quotient_cols(), NC = c.cfg.num_challenges, nzpp = c.num_zs_pp();
     const size_t n = C->n;
     std::vector<PolyRef> v;
     for (u32 i = 0; i < np; i++) v.push_back({C->d_pre_coeffs, 0, i, 0});
-    for (u32 i = 0; i < W; i++) v.push_back({i < C->active_wires ? C->d_wcoef : nullptr, (size_t)C->active_wires * n, i, 0});
-    for (u32 i = 0; i < nzpp; i++) v.push_back({C->d_zcoef, (size_t)zc * n, i, 0});
-    for (u32 i = 0; i < qc; i++) v.push_back({C->d_qcoef, (size_t)qc * n, i, 0});
-    for (u32 i = nzpp; i < zc; i++) v.push_back({C->d_zcoef, (size_t)zc * n, i, 0});
+    for (u32 i = 0; i < W; i++) v.push_back({i < C->active_wires ? C->cur->d_wcoef : nullptr, (size_t)C->active_wires * n, i, 0});
+    for (u32 i = 0; i < nzpp; i++) v.push_back({C->cur->d_zcoef, (size_t)zc * n, i, 0});
+    for (u32 i = 0; i < qc; i++) v.push_back({C->cur->d_qcoef, (size_t)qc * n, i, 0});
+    for (u32 i = nzpp; i < zc; i++) v.push_back({C->cur->d_zcoef, (size_t)zc * n, i, 0});
     C->n_b0 = (u32)v.size();
-    for (u32 i = 0; i < NC; i++) v.push_back({C->d_zcoef, (size_t)zc * n, i, 0});
-    for (u32 i = nzpp; i < zc; i++) v.push_back({C->d_zcoef, (size_t)zc * n, i, 0});
+    for (u32 i = 0; i < NC; i++) v.push_back({C->cur->d_zcoef, (size_t)zc * n, i, 0});
+    for (u32 i = nzpp; i < zc; i++) v.push_back({C->cur->d_zcoef, (size_t)zc * n, i, 0});
     C->n_b1 = (u32)v.size() - C->n_b0;
-    return upload(C, &C->d_polyrefs, v.data(), v.size());
+    return upload(C, &C->cur->d_polyrefs, v.data(), v.size());
 }
 
 int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets, size_t n_targets, const uint64_t* d_values, uint8_t* d_proofs, int* d_status,
@@ -806,14 +833,22 @@ int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets,
         if (slot < 0) return set_error("input target is not a target of this circuit"), P2_ERR_INVALID;
         slots[i] = (u32)slot;
     }
-    size_t chunk = C->chunk ? C->chunk : std::min<size_t>(std::max<size_t>(batch, 1), 32);
-    if (alloc_workspace(C, chunk, (u32)n_targets)) return P2_ERR_HIP;
-    if (setup_polyrefs(C)) return P2_ERR_HIP;
-    HIPCHECK(hipMemcpyAsync(C->d_input_slots, slots.data(), n_targets * 4, hipMemcpyHostToDevice, C->stream));
-    HIPCHECK(hipStreamSynchronize(C->stream));  // `slots` is a stack-lifetime host buffer
-    for (size_t done = 0; done < batch; done += C->chunk) {
+    // chunk size / stream count: P2AES_CHUNK (default 32 proofs), P2AES_STREAMS (default 2)
+    size_t want_chunk = 32, want_streams = 2;
+    if (const char* e = getenv("P2AES_CHUNK")) want_chunk = std::max(1, atoi(e));
+    if (const char* e = getenv("P2AES_STREAMS")) want_streams = std::min(8, std::max(1, atoi(e)));
+    size_t chunk = C->chunk ? C->chunk : std::min<size_t>(std::max<size_t>(batch, 1), want_chunk);
+    size_t nstreams = C->chunk ? C->ws.size() : std::min(want_streams, (batch + chunk - 1) / chunk);
+    if (alloc_workspace(C, chunk, (u32)n_targets, nstreams)) return P2_ERR_HIP;
+    HIPCHECK(hipMemcpy(C->d_input_slots, slots.data(), n_targets * 4, hipMemcpyHostToDevice));
+    // the caller's inputs may have been produced on another stream (torch's current stream): make them visible
+    HIPCHECK(hipDeviceSynchronize());
+    size_t k = 0;
+    for (size_t done = 0; done < batch; done += C->chunk, k++) {
         u32 B = (u32)std::min(C->chunk, batch - done);
+        C->cur = C->ws[k % C->ws.size()];
         int rc = prove_chunk(C, B, (u32)n_targets, d_values + done * n_targets, d_proofs + done * C->pbytes, d_status + done);
+        C->cur = nullptr;
         if (rc) return rc;
     }
     return P2_OK;
@@ -822,6 +857,7 @@ int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets,
 int p2_circuit_synchronize(p2_circuit* C) {
     HIPCHECK(hipSetDevice(C->device));
     HIPCHECK(hipStreamSynchronize(C->stream));
+    for (Workspace* W : C->ws) HIPCHECK(hipStreamSynchronize(W->stream));
     if (C->timing_on) collect_timing(C);
     return P2_OK;
 }
@@ -880,29 +916,38 @@ size_t p2_circuit_get_timing(p2_circuit* C, p2_kernel_time* out, size_t cap) {
 
 int p2_circuit_debug_read(p2_circuit* C, const char* name_c, size_t index, uint64_t* out, size_t cap, size_t* n_written) {
     HIPCHECK(hipSetDevice(C->device));
-    HIPCHECK(hipStreamSynchronize(C->stream));
+    HIPCHECK(hipDeviceSynchronize());
     const Circuit& c = C->c;
     std::string name(name_c);
+    // `index` addresses proof (index % chunk) of the workspace that handled chunk (index / chunk) of the last call
+    struct CurGuard {
+        p2_circuit* C;
+        ~CurGuard() { C->cur = nullptr; }
+    } guard{C};
+    if (!C->ws.empty()) {
+        C->cur = C->ws[(index / C->chunk) % C->ws.size()];
+        index %= C->chunk;
+    }
     const size_t n = C->n, N = C->N;
     const u32 zc = c.num_zs_cols(), qc = c.num_quotient_cols(), act = C->active_wires, cap_words = 4u << c.cfg.cap_height;
     const u64* src = nullptr;
     size_t count = 0;
     if (name == "pre_cap") { src = C->pre_tree.dig + cap_off(C->pre_tree, c.cfg.cap_height); count = cap_words; }
     else if (name == "pre_coeffs") { src = C->d_pre_coeffs; count = (size_t)c.num_preprocessed() * n; }
-    else if (index >= C->chunk) return set_error("index beyond the last chunk"), P2_ERR_INVALID;
-    else if (name == "values") { src = C->d_values + index * c.num_slots; count = c.num_slots; }
-    else if (name == "wires") { src = C->d_wires + index * act * n; count = (size_t)act * n; }
-    else if (name == "wires_coeffs") { src = C->d_wcoef + index * act * n; count = (size_t)act * n; }
-    else if (name == "wires_lde") { src = C->d_wlde + index * act * N; count = (size_t)act * N; }
-    else if (name == "wires_cap") { src = C->wtree.dig + index * C->wtree.stride() + cap_off(C->wtree, c.cfg.cap_height); count = cap_words; }
-    else if (name == "zs") { src = C->d_zs + index * zc * n; count = (size_t)zc * n; }
-    else if (name == "zs_cap") { src = C->ztree.dig + index * C->ztree.stride() + cap_off(C->ztree, c.cfg.cap_height); count = cap_words; }
-    else if (name == "quotient_values") { src = C->d_qvals + index * 2 * N; count = 2 * N; }
-    else if (name == "quotient_coeffs") { src = C->d_qcoef + index * qc * n; count = (size_t)qc * n; }
-    else if (name == "quotient_cap") { src = C->qtree.dig + index * C->qtree.stride() + cap_off(C->qtree, c.cfg.cap_height); count = cap_words; }
-    else if (name == "challenges") { src = C->d_chal + index * CH_WORDS; count = CH_WORDS; }
-    else if (name == "openings") { src = C->d_ev + index * 2 * C->ev_count; count = 2 * (size_t)C->ev_count; }
-    else if (name == "fri_final_poly_in") { src = C->d_fri_coef[0] + index * 2 * n; count = 2 * n; }
+    else if (C->ws.empty()) return set_error("nothing has been proven yet"), P2_ERR_INVALID;
+    else if (name == "values") { src = C->cur->d_values + index * c.num_slots; count = c.num_slots; }
+    else if (name == "wires") { src = C->cur->d_wires + index * act * n; count = (size_t)act * n; }
+    else if (name == "wires_coeffs") { src = C->cur->d_wcoef + index * act * n; count = (size_t)act * n; }
+    else if (name == "wires_lde") { src = C->cur->d_wlde + index * act * N; count = (size_t)act * N; }
+    else if (name == "wires_cap") { src = C->cur->wtree.dig + index * C->cur->wtree.stride() + cap_off(C->cur->wtree, c.cfg.cap_height); count = cap_words; }
+    else if (name == "zs") { src = C->cur->d_zs + index * zc * n; count = (size_t)zc * n; }
+    else if (name == "zs_cap") { src = C->cur->ztree.dig + index * C->cur->ztree.stride() + cap_off(C->cur->ztree, c.cfg.cap_height); count = cap_words; }
+    else if (name == "quotient_values") { src = C->cur->d_qvals + index * 2 * N; count = 2 * N; }
+    else if (name == "quotient_coeffs") { src = C->cur->d_qcoef + index * qc * n; count = (size_t)qc * n; }
+    else if (name == "quotient_cap") { src = C->cur->qtree.dig + index * C->cur->qtree.stride() + cap_off(C->cur->qtree, c.cfg.cap_height); count = cap_words; }
+    else if (name == "challenges") { src = C->cur->d_chal + index * CH_WORDS; count = CH_WORDS; }
+    else if (name == "openings") { src = C->cur->d_ev + index * 2 * C->ev_count; count = 2 * (size_t)C->ev_count; }
+    else if (name == "fri_final_poly_in") { src = C->cur->d_fri_coef[0] + index * 2 * n; count = 2 * n; }
     else return set_error("unknown debug buffer"), P2_ERR_INVALID;
     if (count > cap) return set_error("debug buffer too small"), P2_ERR_INVALID;
     HIPCHECK(hipMemcpy(out, src, count * 8, hipMemcpyDeviceToHost));

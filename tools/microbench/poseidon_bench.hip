@@ -1,0 +1,49 @@
+// Times Poseidon permutation variants on device-resident states (throughput in Gperm/s) and cross-checks them.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+#include "../../plonky2-aes_amd/csrc/gl.h"
+#include "../../plonky2-aes_amd/csrc/poseidon_fast.h"
+typedef gl::u64 u64;
+// states stored column-major [12][n] so that loads are coalesced, like the leaf-hash kernel's column reads
+template <int V>
+__global__ __launch_bounds__(256) void k(const u64* in, u64* out, size_t n, int reps) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 s[12];
+#pragma unroll
+    for (int k_ = 0; k_ < 12; k_++) s[k_] = in[(size_t)k_ * n + i];
+    for (int r = 0; r < reps; r++) {
+        if (V == 0) gl::poseidon(s);
+        else glf::poseidon(s);
+    }
+#pragma unroll
+    for (int k_ = 0; k_ < 12; k_++) out[(size_t)k_ * n + i] = s[k_];
+}
+int main() {
+    size_t n = 1 << 21;
+    int reps = 4;
+    std::vector<u64> h(12 * n);
+    u64 x = 88172645463325252ull;
+    for (auto& v : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = x % gl::P; }
+    u64 *d_in, *d0, *d1;
+    hipMalloc(&d_in, 96 * n); hipMalloc(&d0, 96 * n); hipMalloc(&d1, 96 * n);
+    hipMemcpy(d_in, h.data(), 96 * n, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms[2];
+    for (int v = 0; v < 2; v++) {
+        for (int it = 0; it < 2; it++) {
+            hipEventRecord(e0);
+            if (v == 0) hipLaunchKernelGGL(k<0>, dim3(n / 256), dim3(256), 0, 0, d_in, d0, n, reps);
+            else hipLaunchKernelGGL(k<1>, dim3(n / 256), dim3(256), 0, 0, d_in, d1, n, reps);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms[v], e0, e1);
+        }
+        printf("variant %d: %.3f ms for %zu perms -> %.3f Gperm/s\n", v, ms[v], n * reps, n * reps / ms[v] / 1e6);
+    }
+    std::vector<u64> a(12 * n), b(12 * n);
+    hipMemcpy(a.data(), d0, 96 * n, hipMemcpyDeviceToHost); hipMemcpy(b.data(), d1, 96 * n, hipMemcpyDeviceToHost);
+    size_t bad = 0; for (size_t i = 0; i < 12 * n; i++) bad += a[i] != b[i];
+    printf("mismatches between variants: %zu\n", bad);
+    return bad != 0;
+}
