@@ -169,6 +169,72 @@ __global__ __launch_bounds__(1024) void k_ntt_lds(NttArgs a) {
     }
 }
 
+// ---- large transforms (n > 2^14): four-step split n = n1 * n2.  Pass 1 (this kernel): for a tile of T adjacent
+// columns j2, the n1-point DIF over the stride-n2 elements x[j1*n2 + j2], then the twiddle w_n^(j2*k1); the result
+// for k1 lands in row rev(k1).  Pass 2 is k_ntt_lds on the n1 contiguous rows of n2 points.  Together: natural
+// order in, bit-reversed order out, exactly like the single-pass kernel.
+struct Pass1Args {
+    const u64* in;
+    u64* out;
+    const u64* tw;   // w^i for i < n (forward or inverse root of order n)
+    const u64* pre;  // [cosets][n] scale applied on load, or null
+    size_t in_col_stride, out_col_stride, in_batch_stride, out_batch_stride;
+    int logn, log_n1, log_T, cosets, in_coset_blocks;
+    u32 block_of_coset[8];
+};
+__global__ __launch_bounds__(256) void k_ntt_pass1(Pass1Args a) {
+    extern __shared__ __align__(16) u64 lds[];
+    const u32 n = 1u << a.logn, n1 = 1u << a.log_n1, T = 1u << a.log_T;
+    const int log_n2 = a.logn - a.log_n1;
+    const u32 n2 = 1u << log_n2, tiles = n2 >> a.log_T;
+    const u32 tile = blockIdx.x % tiles, cc = blockIdx.x / tiles, col = cc / a.cosets, coset = cc % a.cosets;
+    const u32 blk = a.block_of_coset[coset];
+    const u64* in = a.in + (size_t)blockIdx.y * a.in_batch_stride + (size_t)col * a.in_col_stride + (a.in_coset_blocks ? (size_t)blk * n : 0);
+    u64* out = a.out + (size_t)blockIdx.y * a.out_batch_stride + (size_t)col * a.out_col_stride + (size_t)blk * n;
+    const u64* pre = a.pre ? a.pre + (size_t)coset * n : nullptr;
+    const u32 j2_0 = tile << a.log_T;
+    for (u32 e = threadIdx.x; e < (n1 << a.log_T); e += blockDim.x) {
+        u32 j1 = e >> a.log_T, t = e & (T - 1);
+        size_t idx = (size_t)j1 * n2 + j2_0 + t;
+        u64 v = in[idx];
+        if (pre) v = gl::mul(v, pre[idx]);
+        lds[e] = v;
+    }
+    __syncthreads();
+    for (int s = a.log_n1 - 1; s >= 0; s--) {
+        const u32 h = 1u << s;
+        for (u32 b = threadIdx.x; b < ((n1 >> 1) << a.log_T); b += blockDim.x) {
+            u32 t = b & (T - 1), q = b >> a.log_T;
+            u32 pos = q & (h - 1);
+            u32 i = ((q >> s) << (s + 1)) | pos;
+            u64 x = lds[(i << a.log_T) + t], y = lds[((i + h) << a.log_T) + t];
+            u64 w = a.tw[(size_t)(pos << (a.log_n1 - 1 - s)) << log_n2];  // w_n1^(pos * 2^(log_n1-1-s))
+            lds[(i << a.log_T) + t] = gl::add(x, y);
+            lds[((i + h) << a.log_T) + t] = gl::mul(gl::sub(x, y), w);
+        }
+        __syncthreads();
+    }
+    for (u32 e = threadIdx.x; e < (n1 << a.log_T); e += blockDim.x) {
+        u32 r = e >> a.log_T, t = e & (T - 1);
+        u32 k1 = a.log_n1 ? (__brev(r) >> (32 - a.log_n1)) : 0;
+        u32 j2 = j2_0 + t;
+        out[(size_t)r * n2 + j2] = gl::mul(lds[e], a.tw[(size_t)k1 * j2]);
+    }
+}
+// out[i] = in[rev(i)] (* post[row][i]) on `blocks` consecutive blocks of n per column
+__global__ void k_bitrev_copy(const u64* in, size_t in_col_stride, size_t in_batch_stride, u64* out, size_t out_col_stride, size_t out_batch_stride, int logn,
+                              u32 blocks, const u64* post, u32 post_block_perm /*1: table row = rev3(block)*/) {
+    const size_t n = (size_t)1 << logn;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 col = blockIdx.z / blocks, blk = blockIdx.z % blocks;
+    const u64* src = in + (size_t)blockIdx.y * in_batch_stride + (size_t)col * in_col_stride + (size_t)blk * n;
+    u64* dst = out + (size_t)blockIdx.y * out_batch_stride + (size_t)col * out_col_stride + (size_t)blk * n;
+    u64 v = src[__brev((u32)i) >> (32 - logn)];
+    if (post) v = gl::mul(v, post[(size_t)(post_block_perm ? (__brev(blk) >> 29) : blk) * n + i]);
+    dst[i] = v;
+}
+
 // table[j][i] = (base[j])^i  for i < n   (coset shift powers and their inverses, zeta powers, ...)
 __global__ void k_pow_table(u64* table, const u64* bases, u32 n, u64 scale) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -69,6 +69,8 @@ struct p2_circuit {
     size_t total_lut_entries = 0;
     u64 *d_sigmas = nullptr, *d_k_is = nullptr, *d_subgroup = nullptr;
     u64 *d_tw_fwd = nullptr, *d_tw_inv = nullptr;  // w^k / w^-k for k < n_max/2, n_max = n
+    u64 *d_tw_fwd_full = nullptr, *d_tw_inv_full = nullptr;  // w^k / w^-k for k < n (two-pass NTT, n > 2^14)
+    u64* d_tw_fwd_round[9] = {nullptr};                       // order n_r tables for FRI rounds that still need two passes
     u64* d_shift_pows[9] = {nullptr};              // per FRI round r (0 = main LDE): [8][n_r] (s_r w^j)^i
     u64* d_shift_inv_pows = nullptr;               // [8][n] (g w^j)^-i / n   (quotient inverse)
     u64 *d_xs = nullptr, *d_l0 = nullptr, *d_zh_inv = nullptr, *d_w8inv = nullptr, *d_qscale = nullptr;
@@ -137,8 +139,60 @@ static int run_ntt(p2_circuit* C, const char* name, NttArgs a, u32 cols, u32 bat
     LAUNCH(C, name, k_ntt_lds, dim3(cols * a.cosets, batch), dim3(1024), shmem, a);
     return 0;
 }
-// values [cols][n] -> coeffs [cols][n]
-static int intt_cols(p2_circuit* C, const u64* vals, u64* coeffs, u32 cols, size_t batch_stride, u32 batch) {
+static const u32 LDS_NTT_MAX_BITS = 14;  // whole transform in one workgroup's LDS up to 2^14 points
+// two-pass transform of `cols*cosets` blocks: natural order in `in`, bit-reversed order in `out`
+static int ntt_big(p2_circuit* C, const char* name, const u64* in, u64* out, const u64* tw_full, const u64* pre, u32 logn, u32 cols, u32 cosets,
+                   const u32* block_of_coset, int in_coset_blocks, size_t in_col_stride, size_t out_col_stride, size_t in_batch_stride,
+                   size_t out_batch_stride, u64 post_scalar, u32 batch) {
+    const u32 log_n2 = 12, log_n1 = logn - log_n2;
+    u32 log_T = 12 - log_n1;  // tile of n1 x T = 4096 elements (32 KiB LDS)
+    if (log_T < 2) return set_error("transform too large for the two-pass NTT"), P2_ERR_INVALID;
+    Pass1Args a{};
+    a.in = in;
+    a.out = out;
+    a.tw = tw_full;
+    a.pre = pre;
+    a.in_col_stride = in_col_stride;
+    a.out_col_stride = out_col_stride;
+    a.in_batch_stride = in_batch_stride;
+    a.out_batch_stride = out_batch_stride;
+    a.logn = (int)logn;
+    a.log_n1 = (int)log_n1;
+    a.log_T = (int)log_T;
+    a.cosets = (int)cosets;
+    a.in_coset_blocks = in_coset_blocks;
+    for (u32 j = 0; j < 8; j++) a.block_of_coset[j] = block_of_coset ? block_of_coset[j] : 0;
+    u32 tiles = (1u << log_n2) >> log_T;
+    LAUNCH(C, name, k_ntt_pass1, dim3(tiles * cols * cosets, batch), dim3(256), (size_t)8 << 12, a);
+    // pass 2: every row of n2 contiguous points, in place
+    if (out_col_stride != ((size_t)cosets << logn)) return set_error("internal: two-pass NTT needs densely packed output blocks"), P2_ERR_INVALID;
+    NttArgs b{};
+    b.in = out;
+    b.out = out;
+    b.tw = tw_full;
+    b.post_scalar = post_scalar;
+    b.in_col_stride = b.out_col_stride = (size_t)1 << log_n2;
+    b.in_batch_stride = b.out_batch_stride = out_batch_stride;
+    b.logn = (int)log_n2;
+    b.log_nmax = (int)logn;
+    b.cosets = 1;
+    size_t rows = ((size_t)cols * cosets) << log_n1;
+    // grid.x is limited to 2^31-1; rows*1 fits for every supported size
+    LAUNCH(C, name, k_ntt_lds, dim3((u32)rows, batch), dim3(1024), (size_t)8 << log_n2, b);
+    return 0;
+}
+// values [cols][n] -> coeffs [cols][n].  `scratch` ([cols][n] per proof, same batch stride) is needed when n > 2^14.
+static int intt_cols(p2_circuit* C, const u64* vals, u64* coeffs, u32 cols, size_t batch_stride, u32 batch, u64* scratch = nullptr,
+                     size_t scratch_batch_stride = 0) {
+    if (C->logn > LDS_NTT_MAX_BITS) {
+        if (!scratch) return set_error("internal: large iNTT needs scratch"), P2_ERR_INVALID;
+        if (ntt_big(C, "intt", vals, scratch, C->d_tw_inv_full, nullptr, C->logn, cols, 1, nullptr, 0, C->n, C->n, batch_stride, scratch_batch_stride,
+                    gl::inv((u64)C->n % gl::P), batch))
+            return P2_ERR_HIP;
+        LAUNCH(C, "bitrev_copy", k_bitrev_copy, g1(C->n, 256, batch, cols), dim3(256), 0, scratch, C->n, scratch_batch_stride, coeffs, C->n, batch_stride,
+               (int)C->logn, 1u, (const u64*)nullptr, 0u);
+        return 0;
+    }
     NttArgs a{};
     a.in = vals;
     a.out = coeffs;
@@ -155,6 +209,15 @@ static int intt_cols(p2_circuit* C, const u64* vals, u64* coeffs, u32 cols, size
 static int lde_cols(p2_circuit* C, const u64* coeffs, size_t in_batch_stride, u64* lde, size_t out_batch_stride, u32 cols, u32 round, u32 batch) {
     u32 logn_r = C->logn;
     for (u32 r = 0; r < round; r++) logn_r -= C->arities[r];
+    u32 blocks[8];
+    for (u32 j = 0; j < 8; j++) blocks[j] = gl::bitrev(j, (int)C->c.cfg.rate_bits);
+    if (logn_r > LDS_NTT_MAX_BITS) {
+        // twiddles of order n_r are a stride of the order-n table
+        if (round != 0 && C->d_tw_fwd_round[round] == nullptr) return set_error("internal: missing round twiddles"), P2_ERR_INVALID;
+        const u64* tw = round == 0 ? C->d_tw_fwd_full : C->d_tw_fwd_round[round];
+        return ntt_big(C, "lde", coeffs, lde, tw, C->d_shift_pows[round], logn_r, cols, 8, blocks, 0, (size_t)1 << logn_r, (size_t)8 << logn_r,
+                       in_batch_stride, out_batch_stride, 1, batch);
+    }
     NttArgs a{};
     a.in = coeffs;
     a.out = lde;
@@ -167,7 +230,7 @@ static int lde_cols(p2_circuit* C, const u64* coeffs, size_t in_batch_stride, u6
     a.out_batch_stride = out_batch_stride;
     a.logn = (int)logn_r;
     a.cosets = 1 << C->c.cfg.rate_bits;
-    for (u32 j = 0; j < 8; j++) a.block_of_coset[j] = gl::bitrev(j, (int)C->c.cfg.rate_bits);
+    for (u32 j = 0; j < 8; j++) a.block_of_coset[j] = blocks[j];
     return run_ntt(C, "lde", a, cols, batch);
 }
 static int merkle_build(p2_circuit* C, const u64* data, u32 cols, u32 active, size_t col_stride, size_t batch_stride, Tree& t, u32 batch) {
@@ -233,20 +296,30 @@ static int circuit_setup(p2_circuit* C) {
     if (upload(C, &C->d_k_is, c.k_is.data(), c.k_is.size())) return P2_ERR_HIP;
     // twiddles, subgroup, coset tables (host-computed once; O(n) field ops)
     {
-        std::vector<u64> sub(n), twf(std::max<size_t>(n / 2, 1)), twi(std::max<size_t>(n / 2, 1));
+        std::vector<u64> sub(n), twi(n);
         u64 w = gl::root_of_unity((int)C->logn), wi = gl::inv(w), x = 1, xi = 1;
         for (size_t i = 0; i < n; i++) {
             sub[i] = x;
-            if (i < n / 2) {
-                twf[i] = x;
-                twi[i] = xi;
-            }
+            twi[i] = xi;
             x = gl::mul(x, w);
             xi = gl::mul(xi, wi);
         }
         if (upload(C, &C->d_subgroup, sub.data(), n)) return P2_ERR_HIP;
-        if (upload(C, &C->d_tw_fwd, twf.data(), twf.size())) return P2_ERR_HIP;
-        if (upload(C, &C->d_tw_inv, twi.data(), twi.size())) return P2_ERR_HIP;
+        if (upload(C, &C->d_tw_inv_full, twi.data(), n)) return P2_ERR_HIP;
+        C->d_tw_fwd_full = C->d_subgroup;  // w^k, k < n
+        C->d_tw_fwd = C->d_tw_fwd_full;    // the single-pass kernel only indexes k < n/2
+        C->d_tw_inv = C->d_tw_inv_full;
+        // FRI rounds whose polynomial is still > 2^14 need their own order-n_r table
+        u32 logn_r = C->logn;
+        for (u32 r = 0; r < C->arities.size(); r++) {
+            logn_r -= C->arities[r];
+            if (logn_r > LDS_NTT_MAX_BITS) {
+                size_t n_r = (size_t)1 << logn_r;
+                std::vector<u64> t(n_r);
+                for (size_t i = 0; i < n_r; i++) t[i] = sub[i << (C->logn - logn_r)];
+                if (upload(C, &C->d_tw_fwd_round[r + 1], t.data(), n_r)) return P2_ERR_HIP;
+            }
+        }
     }
     {
         // LDE shift tables for round r: bases s_{r,j} = g^(16^r) * w_{8 n_r}^j
@@ -326,7 +399,7 @@ static int circuit_setup(p2_circuit* C) {
         if (dalloc(C, &C->d_pre_lde, (size_t)np * N)) return P2_ERR_HIP;
         C->pre_tree.bits = C->lde_bits;
         if (dalloc(C, &C->pre_tree.dig, C->pre_tree.stride())) return P2_ERR_HIP;
-        if (intt_cols(C, d_vals, C->d_pre_coeffs, np, 0, 1)) return P2_ERR_HIP;
+        if (intt_cols(C, d_vals, C->d_pre_coeffs, np, 0, 1, C->d_pre_lde, 0)) return P2_ERR_HIP;
         if (lde_cols(C, C->d_pre_coeffs, 0, C->d_pre_lde, 0, np, 0, 1)) return P2_ERR_HIP;
         if (merkle_build(C, C->d_pre_lde, np, np, N, 0, C->pre_tree, 1)) return P2_ERR_HIP;
         HIPCHECK(hipStreamSynchronize(C->stream));
@@ -465,7 +538,7 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         LAUNCH(C, "lut_rows", k_lut_rows, g1(std::max<size_t>(C->total_lut_entries, 256), 256, B), dim3(256), 0, a);
     }
     // 2. wires commitment
-    if (intt_cols(C, C->cur->d_wires, C->cur->d_wcoef, act, ws, B)) return P2_ERR_HIP;
+    if (intt_cols(C, C->cur->d_wires, C->cur->d_wcoef, act, ws, B, C->cur->d_wlde, wls)) return P2_ERR_HIP;
     if (lde_cols(C, C->cur->d_wcoef, ws, C->cur->d_wlde, wls, act, 0, B)) return P2_ERR_HIP;
     if (merkle_build(C, C->cur->d_wlde, c.cfg.num_wires, act, N, wls, C->cur->wtree, B)) return P2_ERR_HIP;
     // 3. betas, gammas, deltas
@@ -497,7 +570,7 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         LAUNCH(C, "lookup_scan", k_lookup_scan, dim3((u32)c.luts.size(), B, NC), dim3(1024), 0, a);
     }
     // 6. zs commitment, alphas
-    if (intt_cols(C, C->cur->d_zs, C->cur->d_zcoef, zc, zs_s, B)) return P2_ERR_HIP;
+    if (intt_cols(C, C->cur->d_zs, C->cur->d_zcoef, zc, zs_s, B, C->cur->d_zlde, zl_s)) return P2_ERR_HIP;
     if (lde_cols(C, C->cur->d_zcoef, zs_s, C->cur->d_zlde, zl_s, zc, 0, B)) return P2_ERR_HIP;
     if (merkle_build(C, C->cur->d_zlde, zc, zc, N, zl_s, C->cur->ztree, B)) return P2_ERR_HIP;
     if (challenger(C, 1, C->cur->ztree.dig + cap_off(C->cur->ztree, cap_h), C->cur->ztree.stride(), cap_words, 0, 0, B)) return P2_ERR_HIP;
@@ -543,6 +616,15 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         a.zs_values_batch_stride = zs_s;
         LAUNCH(C, "quotient", k_quotient, g1(N, 256, B), dim3(256), 0, a);
         // coset-wise inverse transform: residues r_j, then the 8-point cross-coset DFT
+        if (C->logn > LDS_NTT_MAX_BITS) {
+            const size_t qs = (size_t)NC * N;
+            u32 ident[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+            LAUNCH(C, "bitrev_copy", k_bitrev_copy, g1(n, 256, B, NC * 8), dim3(256), 0, C->cur->d_qvals, N, qs, C->cur->d_qres, N, qs, (int)C->logn, 8u,
+                   (const u64*)nullptr, 0u);
+            if (ntt_big(C, "quotient_intt", C->cur->d_qres, C->cur->d_qvals, C->d_tw_inv_full, nullptr, C->logn, NC, 8, ident, 1, N, N, qs, qs, 1, B)) return P2_ERR_HIP;
+            LAUNCH(C, "bitrev_copy", k_bitrev_copy, g1(n, 256, B, NC * 8), dim3(256), 0, C->cur->d_qvals, N, qs, C->cur->d_qres, N, qs, (int)C->logn, 8u,
+                   (const u64*)C->d_shift_inv_pows, 1u);
+        } else {
         NttArgs t{};
         t.in = C->cur->d_qvals;
         t.out = C->cur->d_qres;
@@ -556,10 +638,10 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         t.bitrev_in = 1;
         t.bitrev_out = 1;
         t.in_coset_blocks = 1;
-        // input block rev3(j) holds coset j; residue r_j is written to block j
+        // input block rev3(j) holds coset j; residue r_j is written to the same block
         for (u32 j = 0; j < 8; j++) t.block_of_coset[j] = gl::bitrev(j, 3);
-        // (output uses the same block index; k_quotient_chunks reads block rev3(j) as coset j)
         if (run_ntt(C, "quotient_intt", t, NC, B)) return P2_ERR_HIP;
+        }
         LAUNCH(C, "quotient_chunks", k_quotient_chunks_rev, g1(n, 256, B, NC), dim3(256), 0, C->cur->d_qres, C->cur->d_qcoef, (u32)n, (size_t)NC * N, (size_t)qc * n,
                C->d_w8inv, C->d_qscale);
     }
@@ -724,7 +806,7 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
         if (c.cfg.rate_bits != 3 || c.cfg.num_challenges != 2 || c.cfg.quotient_degree_factor != 8 || c.cfg.num_routed_wires != 80 || c.cfg.arity_bits != 4 ||
             c.cfg.num_query_rounds > 64 || c.gates.size() > 8 || c.luts.size() > 6)
             throw std::runtime_error("only CircuitConfig::standard_recursion_config() is supported");
-        if (c.degree_bits > 14) throw std::runtime_error("degree_bits > 14 needs the multi-pass NTT (not built yet)");
+        if (c.degree_bits > 22) throw std::runtime_error("degree_bits > 22 is not supported");
         C->device = device;
         C->logn = c.degree_bits;
         C->n = c.n();
@@ -737,6 +819,8 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
         if (hipStreamCreate(&C->stream) != hipSuccess) throw std::runtime_error("hipStreamCreate failed");
         if (hipFuncSetAttribute((const void*)k_ntt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
             throw std::runtime_error("cannot raise the dynamic LDS limit to 128 KiB");
+        if (hipFuncSetAttribute((const void*)k_ntt_pass1, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+            throw std::runtime_error("cannot set the dynamic LDS limit of the pass-1 NTT");
         // opening maps
         const u32 np = c.num_preprocessed(), W = c.cfg.num_wires, zc = c.num_zs_cols(), qc = c.num_quotient_cols(), NC = c.cfg.num_challenges;
         const u32 ncc = c.num_constants_cols(), nzpp = c.num_zs_pp();
@@ -837,6 +921,18 @@ int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets,
     size_t want_chunk = 32, want_streams = 2;
     if (const char* e = getenv("P2AES_CHUNK")) want_chunk = std::max(1, atoi(e));
     if (const char* e = getenv("P2AES_STREAMS")) want_streams = std::min(8, std::max(1, atoi(e)));
+    {
+        // cap the chunk so that all workspaces fit in ~70% of the free HBM
+        const Circuit& c = C->c;
+        size_t n = C->n, N = C->N, zc = c.num_zs_cols(), qc = c.num_quotient_cols(), act = C->active_wires, NC = c.cfg.num_challenges;
+        size_t words = c.num_slots + (act + zc) * 2 * n + qc * n + (act + zc + qc) * N + NC * (c.num_partial_products() + c.num_sldc_polys() + 2) * n +
+                       2 * NC * N + 3 * 8 * N + 16 * n + 4 * N;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && !C->chunk) {
+            size_t fit = (size_t)(0.7 * (double)free_b) / (8 * words * want_streams);
+            want_chunk = std::max<size_t>(1, std::min(want_chunk, fit));
+        }
+    }
     size_t chunk = C->chunk ? C->chunk : std::min<size_t>(std::max<size_t>(batch, 1), want_chunk);
     size_t nstreams = C->chunk ? C->ws.size() : std::min(want_streams, (batch + chunk - 1) / chunk);
     if (alloc_workspace(C, chunk, (u32)n_targets, nstreams)) return P2_ERR_HIP;
@@ -988,15 +1084,17 @@ struct PrimCtx {
         HIPCHECK(hipStreamCreate(&C.stream));
         HIPCHECK(hipFuncSetAttribute((const void*)k_ntt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         size_t n = C.n;
-        std::vector<u64> twf(std::max<size_t>(n / 2, 1)), twi(std::max<size_t>(n / 2, 1));
+        std::vector<u64> twf(n), twi(n);
         u64 w = gl::root_of_unity(degree_bits), wi = gl::inv(w), x = 1, xi = 1;
-        for (size_t i = 0; i < n / 2; i++) {
+        for (size_t i = 0; i < n; i++) {
             twf[i] = x;
             twi[i] = xi;
             x = gl::mul(x, w);
             xi = gl::mul(xi, wi);
         }
-        if (upload(&C, &C.d_tw_fwd, twf.data(), twf.size()) || upload(&C, &C.d_tw_inv, twi.data(), twi.size())) return P2_ERR_HIP;
+        if (upload(&C, &C.d_tw_fwd_full, twf.data(), n) || upload(&C, &C.d_tw_inv_full, twi.data(), n)) return P2_ERR_HIP;
+        C.d_tw_fwd = C.d_tw_fwd_full;
+        C.d_tw_inv = C.d_tw_inv_full;
         std::vector<u64> bases(8);
         u64 wl = gl::root_of_unity(degree_bits + 3);
         for (u32 j = 0; j < 8; j++) bases[j] = gl::mul(gl::MULT_GEN, gl::pow(wl, j));
@@ -1014,20 +1112,20 @@ struct PrimCtx {
     }
 };
 int p2_gpu_intt(const uint64_t* values, size_t cols, int degree_bits, uint64_t* coeffs, int device) {
-    if (degree_bits < 1 || degree_bits > 14) return set_error("degree_bits must be in 1..14"), P2_ERR_INVALID;
+    if (degree_bits < 1 || degree_bits > 22) return set_error("degree_bits must be in 1..22"), P2_ERR_INVALID;
     PrimCtx ctx;
     if (int rc = ctx.init(device, degree_bits)) return rc;
     p2_circuit* C = &ctx.C;
     size_t n = C->n;
-    u64 *d_in, *d_out;
-    if (upload(C, &d_in, values, cols * n) || dalloc(C, &d_out, cols * n)) return P2_ERR_HIP;
-    if (intt_cols(C, d_in, d_out, (u32)cols, 0, 1)) return P2_ERR_HIP;
+    u64 *d_in, *d_out, *d_scratch;
+    if (upload(C, &d_in, values, cols * n) || dalloc(C, &d_out, cols * n) || dalloc(C, &d_scratch, cols * n)) return P2_ERR_HIP;
+    if (intt_cols(C, d_in, d_out, (u32)cols, 0, 1, d_scratch, 0)) return P2_ERR_HIP;
     HIPCHECK(hipStreamSynchronize(C->stream));
     HIPCHECK(hipMemcpy(coeffs, d_out, cols * n * 8, hipMemcpyDeviceToHost));
     return P2_OK;
 }
 int p2_gpu_lde(const uint64_t* coeffs, size_t cols, int degree_bits, int rate_bits, uint64_t* lde, int device) {
-    if (degree_bits < 1 || degree_bits > 14 || rate_bits != 3) return set_error("degree_bits must be in 1..14 and rate_bits 3"), P2_ERR_INVALID;
+    if (degree_bits < 1 || degree_bits > 22 || rate_bits != 3) return set_error("degree_bits must be in 1..22 and rate_bits 3"), P2_ERR_INVALID;
     PrimCtx ctx;
     if (int rc = ctx.init(device, degree_bits)) return rc;
     p2_circuit* C = &ctx.C;

@@ -44,13 +44,14 @@ def test_poseidon_permutation(gpu, orc):
         assert list(s) == list(buf[12 * i:12 * i + 12])
 
 
-@pytest.mark.parametrize("bits", [1, 2, 4, 7, 11, 14])
+@pytest.mark.parametrize("bits", [1, 2, 4, 7, 11, 14, 15, 17])
 def test_intt_and_lde(gpu, orc, bits):
     r = random.Random(bits)
-    cols, n = 5, 1 << bits
+    cols, n = (5 if bits <= 14 else 2), 1 << bits   # > 14 bits exercises the two-pass (four-step) transform
     vals = [r.randrange(P) for _ in range(cols * n)]
-    vals[:n] = [0] * n                       # an all-zero column
-    vals[n:2 * n] = [P - 1] * n              # and a saturated one
+    if cols > 2:
+        vals[:n] = [0] * n                       # an all-zero column
+        vals[n:2 * n] = [P - 1] * n              # and a saturated one
     arr = (C.c_uint64 * len(vals))(*vals)
     out = (C.c_uint64 * len(vals))()
     assert gpu.lib().p2_gpu_intt(arr, cols, bits, out, 0) == 0, gpu.lib().p2_last_error()
@@ -68,7 +69,7 @@ def test_intt_and_lde(gpu, orc, bits):
 def test_intt_rejects_unsupported_sizes(gpu):
     arr = (C.c_uint64 * 4)()
     assert gpu.lib().p2_gpu_intt(arr, 1, 0, arr, 0) != 0
-    assert gpu.lib().p2_gpu_intt(arr, 1, 15, arr, 0) != 0
+    assert gpu.lib().p2_gpu_intt(arr, 1, 23, arr, 0) != 0
 
 
 @pytest.mark.parametrize("cols,leaves", [(1, 16), (4, 32), (5, 64), (8, 128), (9, 256), (135, 1024)])
@@ -160,6 +161,13 @@ def test_reference_circuit_tests_bit_exact(gpu, orc, name):
     else:
         data, pws, _ = circuits.encrypt(gpu, 8, 13, True)
     _gpu_vs_oracle(gpu, orc, data, pws[:2])
+
+
+def test_two_pass_ntt_circuit_2_15_rows(gpu, orc):
+    """A circuit above 2^14 rows (AES-GCM-128 with tag, L = 256 -> n = 2^15): every NTT takes the two-pass path."""
+    data, pws, _ = circuits.encrypt(gpu, 4, 256, True)
+    assert data.info["degree_bits"] == 15
+    _gpu_vs_oracle(gpu, orc, data, pws)
 
 
 def test_cavp_vectors_in_circuit(gpu, orc):

@@ -48,8 +48,8 @@ def primitives():
         OL.orc_poseidon(s)
         ref += list(s)
     check("poseidon", list(buf), ref)
-    for bits in (3, 5, 10, 13, 14):
-        cols, nn = 3, 1 << bits
+    for bits in (3, 5, 10, 13, 14, 15, 16):
+        cols, nn = (3 if bits <= 14 else 2), 1 << bits
         vals = [rnd.randrange(P) for _ in range(cols * nn)]
         out = (C.c_uint64 * (cols * nn))()
         assert L.p2_gpu_intt((C.c_uint64 * len(vals))(*vals), cols, bits, out, 0) == 0, L.p2_last_error()
@@ -155,7 +155,7 @@ def main():
         key, nonce, pt = bytes([42] * 16), bytes([111] * 12), bytes([42] * Lp)
         ct, tag = pkg.native.gcm_encrypt(key, nonce, pt)
         b = pkg.CircuitBuilder()
-        t = pkg.AesGcmTarget.build(b, 4, 10, Lp, False)
+        t = pkg.AesGcmTarget.build(b, 4, 10, Lp, len(sys.argv) > 2)
         data = b.build()
         pw = pkg.PartialWitness()
         t.set_targets(pw, key, nonce, pt, ct, tag)
