@@ -86,6 +86,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     L, B = args.plaintext_bytes, args.batch
+    if L > 4096 and args.batch == 64:
+        B = 8  # deep circuits: a proof is ~32x the work and ~7 GB of workspace
     builder = pkg.CircuitBuilder()
     target = pkg.AesGcmTarget.build(builder, 4, 10, L, False)  # AesGcm128Target<L>, aes-gcm/src/lib.rs:19
     data = pkg.CircuitData(builder.build().blob, device=local_rank)

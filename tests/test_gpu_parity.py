@@ -216,3 +216,27 @@ def test_full_size_aes_gcm_1kib_batch(gpu, orc):
     bad.map[k] ^= 0x10
     proofs2, status2 = data.prove_batch([pws[0], bad, pws[2]])
     assert status2 == [0, 1, 0] and proofs2[0] == proofs[0] and proofs2[2] == proofs[2]
+
+
+def test_64kib_deep_circuit_2_19_rows(gpu):
+    """BASELINE.json configs[4] shape: AesGcm128Target<65536> (n = 2^19 rows, 10.7 M witness ops, 951 MB blob).
+    The oracle needs minutes per proof here, so the checks are size-independent properties: the independent verifier
+    accepts, proving is deterministic, distinct witnesses give distinct proofs, a wrong ciphertext byte is an error."""
+    r = random.Random(5)
+    L = 65536
+    keys = [(bytes(r.randrange(256) for _ in range(16)), bytes(r.randrange(256) for _ in range(12)), bytes(r.randrange(256) for _ in range(L)))
+            for _ in range(3)]
+    data, pws, _ = circuits.encrypt(gpu, 4, L, False, keys=keys)
+    assert data.info["degree_bits"] == 19 and data.info["num_fri_rounds"] == 4
+    proofs, status = data.prove_batch(pws)
+    assert status == [0, 0, 0]
+    vd = data.verifier_data()
+    for p in proofs[:2]:
+        data.verify(p, vd)
+    assert len(set(proofs)) == 3
+    bad = gpu.PartialWitness()
+    bad.map = dict(pws[2].map)
+    k = list(bad.map)[16 + 12 + L + 4242]
+    bad.map[k] ^= 0x80
+    proofs2, status2 = data.prove_batch([pws[0], bad])
+    assert status2 == [0, 1] and proofs2[0] == proofs[0]
