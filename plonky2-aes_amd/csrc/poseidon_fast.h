@@ -60,35 +60,59 @@ GL_HD u64 sbox7(u64 x) {
     u64 x2 = mulr(x, x), x3 = mulr(x2, x), x4 = mulr(x2, x2);
     return mulr(x3, x4);
 }
-// 192-bit accumulator for sums of products
+// Accumulator for sums of 64x64-bit products (dot products of a sparse/dense matrix row with the state).
+// Carries are never propagated between words: each of the four 32x32 partial products is accumulated with one
+// v_mad_u64_u32 into its own aligned 64-bit lane (E01: a0*b0, O01: a0*b1 + a1*b0 (weight 2^32), E23: a1*b1 (weight
+// 2^64)) and the carry-out of every mad is counted in a 32-bit counter.  8 VALU instructions per term, no moves; the
+// four carry SGPR pairs are distinct and each is consumed >= 2 issue slots after it is produced, which is the wait
+// gfx950 requires between a VALU SGPR write and its VALU reader (the compiler pads its own carry chains with
+// s_nop/v_mov for this reason).  reduce() folds the five words once.
 struct Acc {
-    u64 lo, hi;
-    u32 top;
+    u64 e01, o01, e23;
+    u32 ce0, co, ce2;
     GL_HD void init() {
-        lo = hi = 0;
-        top = 0;
+        e01 = o01 = e23 = 0;
+        ce0 = co = ce2 = 0;
     }
     GL_HD void fma(u64 a, u64 b) {
-        u64 ph, pl;
-        mul128(a, b, ph, pl);
-        lo += pl;
-        u64 c = lo < pl;
-        hi += c;
-        top += hi < c;
-        hi += ph;
-        top += hi < ph;
+        u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+        unsigned long long s1, s2, s3, s4;
+        asm("v_mad_u64_u32 %[e01], %[s1], %[a0], %[b0], %[e01]\n\t"
+            "v_mad_u64_u32 %[o01], %[s2], %[a0], %[b1], %[o01]\n\t"
+            "v_mad_u64_u32 %[e23], %[s3], %[a1], %[b1], %[e23]\n\t"
+            "v_addc_co_u32_e64 %[ce0], %[s1], 0, %[ce0], %[s1]\n\t"
+            "v_mad_u64_u32 %[o01], %[s4], %[a1], %[b0], %[o01]\n\t"
+            "v_addc_co_u32_e64 %[co], %[s2], 0, %[co], %[s2]\n\t"
+            "v_addc_co_u32_e64 %[ce2], %[s3], 0, %[ce2], %[s3]\n\t"
+            "v_addc_co_u32_e64 %[co], %[s4], 0, %[co], %[s4]"
+            : [e01] "+v"(e01), [o01] "+v"(o01), [e23] "+v"(e23), [ce0] "+v"(ce0), [co] "+v"(co), [ce2] "+v"(ce2), [s1] "=&s"(s1), [s2] "=&s"(s2),
+              [s3] "=&s"(s3), [s4] "=&s"(s4)
+            : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1));
+#else
+        u64 p, t;
+        p = (u64)a0 * b0; t = e01 + p; ce0 += t < p; e01 = t;
+        p = (u64)a0 * b1; t = o01 + p; co += t < p; o01 = t;
+        p = (u64)a1 * b1; t = e23 + p; ce2 += t < p; e23 = t;
+        p = (u64)a1 * b0; t = o01 + p; co += t < p; o01 = t;
+#endif
     }
-    GL_HD void add(u64 a) {
-        lo += a;
-        u64 c = lo < a;
-        hi += c;
-        top += hi < c;
-    }
-    // 2^128 = -2^32 (mod p)
+    // value = e01 + 2^32*o01 + 2^64*(e23 + ce0 + 2^32*co) + 2^128*ce2 ; 2^128 = -2^32 (mod p); result canonical
     GL_HD u64 reduce() const {
-        u64 r = red128(hi, lo);
-        u64 t = (u64)top << 32;  // canonical (top is tiny)
-        r = canon(r);
+        // l = e01 + (o01 << 32)  as (l0, l1), l1 < 2^33
+        u64 olo = o01 << 32, ohi = o01 >> 32;
+        u64 l0 = e01 + olo;
+        u64 l1 = ohi + (l0 < olo);
+        // h = e23 + ce0 + (co << 32)  as (h0, h1), h1 in {0,1,2}
+        u64 add1 = (u64)ce0 + ((u64)co << 32);  // < 2^64 since co < 2^31
+        u64 h0 = e23 + add1;
+        u64 h1 = h0 < add1;
+        // m = l1 + h0 as (m0, m1)
+        u64 m0 = l1 + h0;
+        u64 m1 = m0 < h0;
+        u64 top = m1 + h1 + ce2;  // multiples of 2^128
+        u64 r = canon(red128(m0, l0));
+        u64 t = top << 32;        // canonical: top is tiny
         return r >= t ? r - t : r + (gl::P - t);
     }
 };
