@@ -107,6 +107,17 @@ int p2_gcm_ghash(p2_builder*, size_t xor_lut, size_t shift_lut, size_t bitref_lu
 int p2_aes_gcm_build(p2_builder*, int nk, int nr, size_t L, int with_tag, p2_target* key, p2_target* nonce, p2_target* pt,
                      p2_target* ct, p2_target* tag);
 
+/* ------------------------------------------------------------------ Poseidon hashing / poseidon-cipher (host) */
+/* builder.hash_n_to_m_no_pad::<PoseidonHash>(inputs, m)  (poseidon-cipher/src/circuit.rs:123): PoseidonGate rows */
+int p2_builder_hash_n_to_m_no_pad(p2_builder*, const p2_target* inputs, size_t n, p2_target* outputs, size_t m);
+/* PoseidonEncryptTarget::<L>::build (poseidon-cipher/src/circuit.rs:49).  ks: 10 targets (x then u), m: 5*L,
+ * nonce: 2, ct: 5*(L+1) */
+int p2_poseidon_cipher_build(p2_builder*, size_t L, p2_target* ks, p2_target* m, p2_target* nonce, p2_target* ct);
+/* native hash / cipher (poseidon-cipher/src/lib.rs:41,75,113).  msg: 5*n_msg words; ct: 5*(ceil3(n_msg)+1) words */
+void p2_native_hash_n_to_m_no_pad(const uint64_t* in, size_t n, uint64_t* out, size_t m);
+void p2_native_poseidon_encrypt(const uint64_t* ks10, const uint64_t* msg, size_t n_msg, const uint64_t* nonce2, uint64_t* ct);
+int p2_native_poseidon_decrypt(const uint64_t* ks10, const uint64_t* ct, size_t n_ct, const uint64_t* nonce2, size_t l, uint64_t* msg);
+
 /* ------------------------------------------------------------------ native cipher (host; witness values) */
 uint8_t p2_native_gf_2_8_mul(uint8_t a, uint8_t b);
 void p2_native_aes_key_expansion(const uint8_t* key, int nk, int nr, uint8_t* out /* 16*(nr+1) */);

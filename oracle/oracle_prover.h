@@ -30,7 +30,7 @@ struct OOp {
 struct OLookupRows {
     u32 last_lu, last_lut, first_lut;
 };
-enum { GK_LOOKUP = 0, GK_LOOKUP_TABLE = 1, GK_NOOP = 2, GK_CONSTANT = 3, GK_PUBLIC_INPUT = 4, GK_ARITHMETIC = 5 };
+enum { GK_LOOKUP = 0, GK_LOOKUP_TABLE = 1, GK_NOOP = 2, GK_CONSTANT = 3, GK_PUBLIC_INPUT = 4, GK_ARITHMETIC = 5, GK_POSEIDON = 6 };
 
 struct Reader {
     const uint8_t* p;
@@ -74,6 +74,7 @@ struct OCircuit {
     std::vector<OOp> ops;
     std::vector<u32> level_offsets;
     std::vector<int32_t> vt_slot, wire_slot;
+    std::vector<u32> poseidon_rows;
     // derived
     size_t n;
     int lde_bits;
@@ -123,7 +124,7 @@ static inline OCircuit* load_circuit(const void* blob, size_t len) {
     char magic[8];
     r.get(magic, 8);
     if (memcmp(magic, "P2AESCIR", 8) != 0) throw std::runtime_error("oracle: bad magic");
-    if (r.g32() != 1) throw std::runtime_error("oracle: bad version");
+    if (r.g32() != 2) throw std::runtime_error("oracle: bad version");
     OCircuit* C = new OCircuit();
     r.get(&C->cfg, sizeof(OConfig));
     C->degree_bits = r.g32();
@@ -144,6 +145,7 @@ static inline OCircuit* load_circuit(const void* blob, size_t len) {
     C->level_offsets = r.arr<u32>();
     C->vt_slot = r.arr<int32_t>();
     C->wire_slot = r.arr<int32_t>();
+    C->poseidon_rows = r.arr<u32>();
     C->n = (size_t)1 << C->degree_bits;
     C->lde_bits = C->degree_bits + C->cfg.rate_bits;
     for (auto& lut : C->luts) {
@@ -166,6 +168,55 @@ static inline OCircuit* load_circuit(const void* blob, size_t len) {
     parts.push_back(C->degree_bits);
     C->circuit_digest = hash_no_pad(parts.data(), parts.size());
     return C;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// PoseidonGate (plonky2 gates/poseidon.rs, restated): wires 0..11 in, 12..23 out, 24 swap, 25..28 delta,
+// 29..64 S-box inputs of full rounds 1..3, 65..86 S-box inputs of the 22 partial rounds, 87..134 S-box inputs of the
+// last four full rounds.  `row` holds the 135 wire values; with `fill` the generator's outputs are written, otherwise
+// the 123 constraint values are appended to `out`.
+static inline void mds_apply(u64 st[12]) {
+    u64 nx[12];
+    for (int r = 0; r < 12; r++) {
+        u128 acc = 0;
+        for (int i = 0; i < 12; i++) acc += (u128)st[(i + r) % 12] * MDS_CIRC[i];
+        acc += (u128)st[r] * MDS_DIAG[r];
+        nx[r] = fred(acc);
+    }
+    memcpy(st, nx, sizeof(nx));
+}
+static inline void poseidon_gate_walk(u64* row, bool fill, std::vector<u64>* out) {
+    auto check = [&](u64 computed, int wire) -> u64 {
+        if (fill) {
+            row[wire] = computed;
+            return computed;
+        }
+        out->push_back(fsub(computed, row[wire]));
+        return row[wire];
+    };
+    u64 swap = row[24];
+    if (!fill) out->push_back(fmul(swap, fsub(swap, 1)));
+    u64 st[12];
+    for (int i = 0; i < 4; i++) {
+        u64 d = check(fmul(swap, fsub(row[4 + i], row[i])), 25 + i);
+        st[i] = fadd(row[i], d);
+        st[4 + i] = fsub(row[4 + i], d);
+    }
+    for (int i = 8; i < 12; i++) st[i] = row[i];
+    for (int round = 0; round < 30; round++) {
+        for (int i = 0; i < 12; i++) st[i] = fadd(st[i], ROUND_CONSTANTS[12 * round + i]);
+        if (round < 4) {
+            if (round > 0)
+                for (int i = 0; i < 12; i++) st[i] = check(st[i], 29 + 12 * (round - 1) + i);
+            for (int i = 0; i < 12; i++) st[i] = pow7(st[i]);
+        } else if (round < 26) {
+            st[0] = pow7(check(st[0], 65 + (round - 4)));
+        } else {
+            for (int i = 0; i < 12; i++) st[i] = pow7(check(st[i], 87 + 12 * (round - 26) + i));
+        }
+        mds_apply(st);
+    }
+    for (int i = 0; i < 12; i++) check(st[i], 12 + i);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -194,8 +245,22 @@ static inline int generate_witness(const OCircuit& C, const u64* in_targets, con
         if (in_values[i] >= MODULUS) return 1;
         if (!set((u32)slot, in_values[i])) return 1;
     }
+    std::vector<std::vector<u64>> pos_rows(C.poseidon_rows.size());  // full 135-wire rows written by PoseidonGenerators
     for (const OOp& o : C.ops) {
         u64 r;
+        if (o.kind == 5) {
+            std::vector<u64> roww(C.cfg.num_wires, 0);
+            for (u32 col = 0; col < 12; col++) roww[col] = val[C.wire_slot[col * C.n + o.a]];
+            roww[24] = val[C.wire_slot[24 * C.n + o.a]];
+            for (u32 col = 0; col < 12; col++)
+                if (roww[col] == UNSET) return 2;
+            if (roww[24] == UNSET) return 2;
+            poseidon_gate_walk(roww.data(), true, nullptr);
+            for (u32 col = 12; col < C.cfg.num_routed_wires; col++)
+                if (col != 24 && !set((u32)C.wire_slot[col * C.n + o.a], roww[col])) return 1;
+            pos_rows[o.aux] = roww;
+            continue;
+        }
         switch (o.kind) {
             case 0: {  // arith
                 u64 a = val[o.a], b = val[o.b], c = val[o.c];
@@ -238,6 +303,10 @@ static inline int generate_witness(const OCircuit& C, const u64* in_targets, con
                 wires[c][row] = val[s];
             }
         }
+    for (size_t k = 0; k < C.poseidon_rows.size(); k++) {
+        if (pos_rows[k].empty()) return 2;
+        for (size_t c = R; c < C.cfg.num_wires; c++) wires[c][C.poseidon_rows[k]] = pos_rows[k][c];
+    }
     // LookupTableGate rows (stored upside down), multiplicities, and padding of the last LookupGate
     // (LookupTableGenerator + prover.rs set_lookup_wires)
     for (size_t l = 0; l < C.luts.size(); l++) {
@@ -354,7 +423,7 @@ static inline void eval_vanishing(const OCircuit& C, const Challenges& ch, u64 x
     // gate constraints, each multiplied by its selector filter
     for (size_t gi = 0; gi < C.gates.size(); gi++) {
         u32 kind = C.gates[gi];
-        if (kind != GK_ARITHMETIC && kind != GK_CONSTANT && kind != GK_PUBLIC_INPUT) continue;
+        if (kind != GK_ARITHMETIC && kind != GK_CONSTANT && kind != GK_PUBLIC_INPUT && kind != GK_POSEIDON) continue;
         size_t si = C.selector_index[gi];
         u64 s = v.consts[si], filter = 1;
         for (u32 j = C.groups[si].first; j < C.groups[si].second; j++)
@@ -369,6 +438,10 @@ static inline void eval_vanishing(const OCircuit& C, const Challenges& ch, u64 x
             }
         } else if (kind == GK_CONSTANT) {
             for (int k = 0; k < 2; k++) gate[k] = fadd(gate[k], fmul(filter, fsub(gc[k], v.wires[k])));
+        } else if (kind == GK_POSEIDON) {
+            std::vector<u64> roww(v.wires, v.wires + C.cfg.num_wires), cs;
+            poseidon_gate_walk(roww.data(), false, &cs);
+            for (size_t k = 0; k < cs.size(); k++) gate[k] = fadd(gate[k], fmul(filter, cs[k]));
         } else {
             for (int k = 0; k < 4; k++) gate[k] = fadd(gate[k], fmul(filter, v.wires[k]));  // public_inputs_hash = 0
         }

@@ -9,8 +9,10 @@ from .api import (  # noqa: F401
     CircuitData,
     P2Error,
     PartialWitness,
+    PoseidonEncryptTarget,
     ProveError,
     lib,
     lib_path,
     native,
+    poseidon_native,
 )

@@ -90,6 +90,11 @@ def lib():
         "p2_gcm_gf_2_128_mul": (None, [vp, sz, sz, sz, u64p, u64p, u64p]),
         "p2_gcm_ghash": (C.c_int, [vp, sz, sz, sz, u64p, u64p, sz, u64p]),
         "p2_aes_gcm_build": (C.c_int, [vp, C.c_int, C.c_int, sz, C.c_int, u64p, u64p, u64p, u64p, u64p]),
+        "p2_builder_hash_n_to_m_no_pad": (C.c_int, [vp, u64p, sz, u64p, sz]),
+        "p2_poseidon_cipher_build": (C.c_int, [vp, sz, u64p, u64p, u64p, u64p]),
+        "p2_native_hash_n_to_m_no_pad": (None, [u64p, sz, u64p, sz]),
+        "p2_native_poseidon_encrypt": (None, [u64p, u64p, sz, u64p, u64p]),
+        "p2_native_poseidon_decrypt": (C.c_int, [u64p, u64p, sz, u64p, sz, u64p]),
         "p2_native_gf_2_8_mul": (C.c_uint8, [C.c_uint8, C.c_uint8]),
         "p2_native_aes_key_expansion": (None, [C.c_char_p, C.c_int, C.c_int, C.c_char_p]),
         "p2_native_aes_encrypt_block": (None, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p]),
@@ -231,6 +236,12 @@ class CircuitBuilder:
             raise P2Error(_err())
         return list(out)
 
+    def hash_n_to_m_no_pad(self, inputs, num_outputs):
+        out = (u64 * num_outputs)()
+        if lib().p2_builder_hash_n_to_m_no_pad(self._h, _arr(inputs), len(inputs), out, num_outputs):
+            raise P2Error(_err())
+        return list(out)
+
     def build(self):
         blob, n = u8p(), sz()
         if lib().p2_builder_build(self._h, C.byref(blob), C.byref(n)):
@@ -361,6 +372,53 @@ class AesGcmTarget:
             for t, v in zip(self.tag, tag): pw.set_byte_target(t, v)
         else:
             for t in self.tag: pw.set_byte_target(t, 0)
+
+
+class PoseidonEncryptTarget:
+    """PoseidonEncryptTarget<L> (poseidon-cipher/src/circuit.rs:35-118).  Fq elements are 5-tuples of field elements;
+    the key point `ks` is its two coordinates (x, u)."""
+
+    @staticmethod
+    def build(builder, L):
+        t = PoseidonEncryptTarget()
+        t.L = L
+        ks, m, nonce, ct = (u64 * 10)(), (u64 * (5 * L))(), (u64 * 2)(), (u64 * (5 * (L + 1)))()
+        if lib().p2_poseidon_cipher_build(builder._h, L, ks, m, nonce, ct):
+            raise P2Error(_err())
+        t.ks, t.m, t.nonce, t.ct = list(ks), list(m), list(nonce), list(ct)
+        return t
+
+    def set_targets(self, pw, ks, m, nonce, ct):
+        assert len(m) == self.L and len(ct) == self.L + 1 and len(ks) == 2   # circuit.rs:99-100
+        pw.set_target_arr(self.ks, [v for fq in ks for v in fq])
+        pw.set_target_arr(self.m, [v for fq in m for v in fq])
+        pw.set_target_arr(self.nonce, nonce)
+        pw.set_target_arr(self.ct, [v for fq in ct for v in fq])
+
+
+class poseidon_native:
+    """poseidon-cipher/src/lib.rs through the C ABI."""
+
+    @staticmethod
+    def hash_n_to_m_no_pad(inputs, m):
+        out = (u64 * m)()
+        lib().p2_native_hash_n_to_m_no_pad(_arr(inputs), len(inputs), out, m)
+        return list(out)
+
+    @staticmethod
+    def encrypt(ks, msg, nonce):
+        n = len(msg)
+        nct = (n + 2) // 3 * 3 + 1
+        ct = (u64 * (5 * nct))()
+        lib().p2_native_poseidon_encrypt(_arr([v for fq in ks for v in fq]), _arr([v for fq in msg for v in fq]) if n else (u64 * 1)(), n, _arr(nonce), ct)
+        return [tuple(ct[5 * i:5 * i + 5]) for i in range(nct)]
+
+    @staticmethod
+    def decrypt(ks, ct, nonce, l):
+        msg = (u64 * (5 * max(l, 1)))()
+        if lib().p2_native_poseidon_decrypt(_arr([v for fq in ks for v in fq]), _arr([v for fq in ct for v in fq]), len(ct), _arr(nonce), l, msg):
+            raise P2Error(_err())
+        return [tuple(msg[5 * i:5 * i + 5]) for i in range(l)]
 
 
 class native:

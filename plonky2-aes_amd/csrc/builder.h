@@ -8,6 +8,7 @@
 // Call sites mirrored: aes-gcm/src/circuit_aes.rs:176-358, aes-gcm/src/circuit_gcm.rs:49-425.
 #pragma once
 #include <algorithm>
+#include <array>
 #include <map>
 #include <memory>
 #include <unordered_map>
@@ -138,6 +139,35 @@ class CircuitBuilder {
         return looking_out;
     }
     size_t num_luts() const { return luts_.size(); }
+
+    // ---- hashing (plonky2 gadgets/hash.rs, hash/poseidon.rs AlgebraicHasher::permute_swapped) --------
+    // One PoseidonGate row; swap = false.
+    std::array<Target, 12> permute(const std::array<Target, 12>& inputs) {
+        u32 row = add_gate(G_POSEIDON);
+        connect(zero(), wire_target(row, PG_SWAP));
+        for (u32 i = 0; i < 12; i++) connect(inputs[i], wire_target(row, PG_IN + i));
+        gens_.push_back(Gen{OP_POSEIDON, wire_target(row, PG_OUT), (Target)row, 0, 0, 0, 0, 0});
+        std::array<Target, 12> out;
+        for (u32 i = 0; i < 12; i++) out[i] = wire_target(row, PG_OUT + i);
+        return out;
+    }
+    // Overwrite-mode sponge, rate 8 (poseidon-cipher/src/circuit.rs:123, hashed_elgamal/circuit.rs:42)
+    std::vector<Target> hash_n_to_m_no_pad(const std::vector<Target>& inputs, size_t num_outputs) {
+        std::array<Target, 12> state;
+        state.fill(zero());
+        for (size_t off = 0; off < inputs.size(); off += 8) {
+            for (size_t i = 0; i < 8 && off + i < inputs.size(); i++) state[i] = inputs[off + i];
+            state = permute(state);
+        }
+        std::vector<Target> outputs;
+        for (;;) {
+            for (size_t i = 0; i < 8; i++) {
+                outputs.push_back(state[i]);
+                if (outputs.size() == num_outputs) return outputs;
+            }
+            state = permute(state);
+        }
+    }
 
     // ---- build (plonky2 CircuitBuilder::build) ----------------------------------------------------
     Circuit build();
@@ -432,6 +462,12 @@ inline Circuit CircuitBuilder::build() {
         } else if (g.kind == OP_EQ || g.kind == OP_EQINV) {
             o.a = slot(g.a);
             o.b = slot(g.b);
+        } else if (g.kind == OP_POSEIDON) {
+            u32 row = (u32)g.a;
+            o.a = row;
+            o.aux = (u32)c.poseidon_rows.size();
+            c.poseidon_rows.push_back(row);
+            for (u32 col = 0; col < R; col++) slot(wire_target(row, col));  // every routed wire of the row carries a value
         }
         ops[i] = o;
     }
@@ -450,17 +486,34 @@ inline Circuit CircuitBuilder::build() {
         const size_t M = ops.size();
         std::vector<u32> num_producers(num_slots, 0);
         std::vector<std::vector<u32>> consumers(num_slots);
+        auto wslot = [&](u32 row, u32 col) -> u32 { return (u32)slot_of[find((u32)(V + (u64)row * R + col))]; };
         auto inputs = [&](const Op& o, u32* in) -> int {
             if (o.kind == OP_ARITH) { in[0] = o.a; in[1] = o.b; in[2] = o.c; return 3; }
             if (o.kind == OP_LOOKUP) { in[0] = o.a; return 1; }
             if (o.kind == OP_EQ || o.kind == OP_EQINV) { in[0] = o.a; in[1] = o.b; return 2; }
+            if (o.kind == OP_POSEIDON) {
+                for (u32 k = 0; k < 12; k++) in[k] = wslot(o.a, PG_IN + k);
+                in[12] = wslot(o.a, PG_SWAP);
+                return 13;
+            }
             return 0;
         };
-        for (size_t i = 0; i < M; i++) num_producers[ops[i].out]++;
+        auto outputs = [&](const Op& o, u32* out) -> int {
+            if (o.kind != OP_POSEIDON) { out[0] = o.out; return 1; }
+            int k = 0;
+            for (u32 col = PG_OUT; col < R; col++)
+                if (col != PG_SWAP) out[k++] = wslot(o.a, col);
+            return k;
+        };
+        for (size_t i = 0; i < M; i++) {
+            u32 outs[80];
+            int k = outputs(ops[i], outs);
+            for (int j = 0; j < k; j++) num_producers[outs[j]]++;
+        }
         std::vector<u32> pending(M, 0), level(M, 0), slot_level(num_slots, 0);
         std::vector<uint8_t> slot_ready(num_slots, 0);
         for (size_t i = 0; i < M; i++) {
-            u32 in[3];
+            u32 in[16];
             int k = inputs(ops[i], in);
             for (int j = 0; j < k; j++) {
                 bool dup = false;
@@ -479,19 +532,22 @@ inline Circuit CircuitBuilder::build() {
         u32 max_level = 0;
         while (done < queue.size()) {
             u32 i = queue[done++];
-            u32 in[3];
+            u32 in[16], outs[80];
             int k = inputs(ops[i], in);
+            int ko = outputs(ops[i], outs);
             u32 lv = 0;
             for (int j = 0; j < k; j++) lv = std::max(lv, slot_level[in[j]]);
-            u32 s = ops[i].out;
-            lv = std::max(lv, slot_level[s]);
+            for (int j = 0; j < ko; j++) lv = std::max(lv, slot_level[outs[j]]);
             level[i] = lv;  // ops with only user-set inputs are level 0
             max_level = std::max(max_level, lv);
-            slot_level[s] = lv + 1;
-            if (!slot_ready[s]) {
-                slot_ready[s] = 1;
-                for (u32 cns : consumers[s])
-                    if (--pending[cns] == 0) queue.push_back(cns);
+            for (int j = 0; j < ko; j++) {
+                u32 s = outs[j];
+                slot_level[s] = lv + 1;
+                if (!slot_ready[s]) {
+                    slot_ready[s] = 1;
+                    for (u32 cns : consumers[s])
+                        if (--pending[cns] == 0) queue.push_back(cns);
+                }
             }
         }
         if (done != M) throw std::runtime_error("witness program has a dependency cycle");

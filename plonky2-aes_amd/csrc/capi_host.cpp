@@ -5,6 +5,7 @@
 #include "../../include/p2aes.h"
 #include "aes_gadgets.h"
 #include "capi_common.h"
+#include "poseidon_cipher.h"
 #include "verifier.h"
 
 using namespace p2;
@@ -161,6 +162,53 @@ int p2_aes_gcm_build(p2_builder* b, int nk, int nr, size_t L, int with_tag, p2_t
     } catch (std::exception& e) {
         return set_error(e.what()), P2_ERR_INVALID;
     }
+}
+
+// ---- Poseidon hashing / poseidon-cipher
+int p2_builder_hash_n_to_m_no_pad(p2_builder* b, const p2_target* inputs, size_t n, p2_target* outputs, size_t m) {
+    try {
+        auto o = b->b.hash_n_to_m_no_pad(std::vector<Target>(inputs, inputs + n), m);
+        std::copy(o.begin(), o.end(), outputs);
+        return P2_OK;
+    } catch (std::exception& e) {
+        return set_error(e.what()), P2_ERR_INVALID;
+    }
+}
+int p2_poseidon_cipher_build(p2_builder* b, size_t L, p2_target* ks, p2_target* m, p2_target* nonce, p2_target* ct) {
+    try {
+        auto t = pcipher::PoseidonEncryptTarget::build(b->b, L);
+        for (int i = 0; i < 5; i++) {
+            ks[i] = t.ks_x[i];
+            ks[5 + i] = t.ks_u[i];
+        }
+        for (size_t i = 0; i < L; i++)
+            for (int j = 0; j < 5; j++) m[5 * i + j] = t.m[i][j];
+        nonce[0] = t.nonce[0];
+        nonce[1] = t.nonce[1];
+        for (size_t i = 0; i <= L; i++)
+            for (int j = 0; j < 5; j++) ct[5 * i + j] = t.ct[i][j];
+        return P2_OK;
+    } catch (std::exception& e) {
+        return set_error(e.what()), P2_ERR_INVALID;
+    }
+}
+void p2_native_hash_n_to_m_no_pad(const uint64_t* in, size_t n, uint64_t* out, size_t m) {
+    auto o = pcipher::hash_n_to_m_no_pad(std::vector<u64>(in, in + n), m);
+    std::copy(o.begin(), o.end(), out);
+}
+static pcipher::Fq fq_at(const uint64_t* p) { return pcipher::Fq{p[0], p[1], p[2], p[3], p[4]}; }
+void p2_native_poseidon_encrypt(const uint64_t* ks, const uint64_t* msg, size_t n_msg, const uint64_t* nonce, uint64_t* ct) {
+    std::vector<pcipher::Fq> m(n_msg);
+    for (size_t i = 0; i < n_msg; i++) m[i] = fq_at(msg + 5 * i);
+    auto c = pcipher::encrypt(fq_at(ks), fq_at(ks + 5), m, nonce);
+    for (size_t i = 0; i < c.size(); i++) memcpy(ct + 5 * i, c[i].data(), 40);
+}
+int p2_native_poseidon_decrypt(const uint64_t* ks, const uint64_t* ct, size_t n_ct, const uint64_t* nonce, size_t l, uint64_t* msg) {
+    std::vector<pcipher::Fq> c(n_ct), m;
+    for (size_t i = 0; i < n_ct; i++) c[i] = fq_at(ct + 5 * i);
+    if (n_ct < 1 || l > n_ct - 1 || !pcipher::decrypt(fq_at(ks), fq_at(ks + 5), c, nonce, l, &m)) return set_error("poseidon decrypt: authentication failed"), P2_ERR_VERIFY;
+    for (size_t i = 0; i < m.size(); i++) memcpy(msg + 5 * i, m[i].data(), 40);
+    return P2_OK;
 }
 
 // ---- native cipher

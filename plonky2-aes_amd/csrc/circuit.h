@@ -44,10 +44,14 @@ enum GateKind : u32 {
     G_CONSTANT = 3,      // ConstantGate{2}, degree 1
     G_PUBLIC_INPUT = 4,  // PublicInputGate, degree 1
     G_ARITHMETIC = 5,    // ArithmeticGate{20 ops}, degree 3
-    G_NUM_KINDS = 6
+    G_POSEIDON = 6,      // PoseidonGate (one permutation per row, all 135 wires), degree 7, 123 constraints
+    G_NUM_KINDS = 7
 };
-static inline u32 gate_degree(u32 k) { return k == G_ARITHMETIC ? 3 : (k == G_CONSTANT || k == G_PUBLIC_INPUT) ? 1 : 0; }
-static inline u32 gate_num_constraints(u32 k) { return k == G_ARITHMETIC ? 20 : k == G_CONSTANT ? 2 : k == G_PUBLIC_INPUT ? 4 : 0; }
+static inline u32 gate_degree(u32 k) { return k == G_POSEIDON ? 7 : k == G_ARITHMETIC ? 3 : (k == G_CONSTANT || k == G_PUBLIC_INPUT) ? 1 : 0; }
+static inline u32 gate_num_constraints(u32 k) { return k == G_POSEIDON ? 123 : k == G_ARITHMETIC ? 20 : k == G_CONSTANT ? 2 : k == G_PUBLIC_INPUT ? 4 : 0; }
+// PoseidonGate wire layout (plonky2 gates/poseidon.rs): 12 in | 12 out | swap | 4 delta | 3x12 full-round
+// S-box inputs | 22 partial-round S-box inputs | 4x12 full-round S-box inputs = 135
+static const u32 PG_IN = 0, PG_OUT = 12, PG_SWAP = 24, PG_DELTA = 25, PG_FULL0 = 29, PG_PARTIAL = 65, PG_FULL1 = 87;
 
 static const u32 LU_SLOTS = 40;   // LookupGate::num_slots = num_routed_wires / 2
 static const u32 LUT_SLOTS = 26;  // LookupTableGate::num_slots = num_routed_wires / 3
@@ -61,6 +65,8 @@ enum OpKind : u32 {
     OP_LOOKUP = 2,  // out = lut[aux](a), error if a is not a table input (LookupGenerator)
     OP_EQ = 3,      // out = (a == b)                 (EqualityGenerator.equal)
     OP_EQINV = 4,   // out = a==b ? 0 : 1/(a-b)       (EqualityGenerator.inv)
+    OP_POSEIDON = 5,  // PoseidonGenerator of gate row `a`: reads wires 0..11 and 24 of the row, writes every other wire of
+                      // the row (routed ones through their slots, wires >= 80 into advice block `aux`)
 };
 struct Op {
     u32 kind, out, a, b, c, aux;
@@ -92,6 +98,7 @@ struct Circuit {
     std::vector<u32> level_offsets;              // ops of level l = [level_offsets[l], level_offsets[l+1])
     std::vector<int32_t> vt_slot;                // virtual target index -> slot (or -1)
     std::vector<int32_t> wire_slot;              // [num_routed][n] -> slot (or -1 = unconnected)
+    std::vector<u32> poseidon_rows;              // rows holding a PoseidonGate; index = advice block of the row
 
     u32 n() const { return 1u << degree_bits; }
     u32 num_selectors() const { return (u32)groups.size(); }
@@ -153,7 +160,7 @@ struct BlobReader {
 };
 
 static const char BLOB_MAGIC[8] = {'P', '2', 'A', 'E', 'S', 'C', 'I', 'R'};
-static const u32 BLOB_VERSION = 1;
+static const u32 BLOB_VERSION = 2;
 
 static inline std::vector<uint8_t> serialize(const Circuit& c) {
     BlobWriter w;
@@ -178,6 +185,7 @@ static inline std::vector<uint8_t> serialize(const Circuit& c) {
     w.vec(c.level_offsets);
     w.vec(c.vt_slot);
     w.vec(c.wire_slot);
+    w.vec(c.poseidon_rows);
     return w.buf;
 }
 
@@ -208,6 +216,7 @@ static inline Circuit deserialize(const void* data, size_t len) {
     r.vec(c.level_offsets);
     r.vec(c.vt_slot);
     r.vec(c.wire_slot);
+    r.vec(c.poseidon_rows);
     // shape checks: everything a kernel indexes with is validated here, once.
     size_t n = c.n();
     if (c.degree_bits > 26) throw std::runtime_error("degree_bits too large");
@@ -224,10 +233,16 @@ static inline Circuit deserialize(const void* data, size_t len) {
         if (o.kind == OP_ARITH && (o.a >= c.num_slots || o.b >= c.num_slots || o.c >= c.num_slots)) throw std::runtime_error("op in slot");
         if (o.kind == OP_LOOKUP && (o.a >= c.num_slots || o.aux >= c.luts.size())) throw std::runtime_error("lookup op");
         if ((o.kind == OP_EQ || o.kind == OP_EQINV) && (o.a >= c.num_slots || o.b >= c.num_slots)) throw std::runtime_error("eq op");
-        if (o.kind > OP_EQINV) throw std::runtime_error("op kind");
+        if (o.kind == OP_POSEIDON && (o.a >= n || o.aux >= c.poseidon_rows.size() || c.poseidon_rows[o.aux] != o.a)) throw std::runtime_error("poseidon op");
+        if (o.kind > OP_POSEIDON) throw std::runtime_error("op kind");
     }
     for (auto s : c.wire_slot)
         if (s >= (int32_t)c.num_slots) throw std::runtime_error("wire slot range");
+    for (u32 row : c.poseidon_rows) {
+        if (row >= n) throw std::runtime_error("poseidon row");
+        for (u32 col = 0; col < c.cfg.num_routed_wires; col++)
+            if (c.wire_slot[(size_t)col * n + row] < 0) throw std::runtime_error("poseidon row wire without slot");
+    }
     for (auto s : c.vt_slot)
         if (s >= (int32_t)c.num_slots) throw std::runtime_error("vt slot range");
     if (c.level_offsets.empty() || c.level_offsets.back() != c.ops.size()) throw std::runtime_error("level offsets");

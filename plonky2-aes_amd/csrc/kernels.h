@@ -12,6 +12,7 @@
 #include "circuit.h"
 #include "gl.h"
 #include "poseidon_fast.h"
+#include "poseidon_gate.h"
 
 namespace p2k {
 using gl::E2;
@@ -277,6 +278,9 @@ struct WitnessArgs {
     u32* mult;                // [batch][total_lut_entries] multiplicity counters (zeroed by the caller)
     size_t total_lut_entries;
     int* status;              // [batch]
+    const int32_t* wire_slot; // [80][n] (PoseidonGate rows read/write their wires through it)
+    u64* advice;              // [batch][num_poseidon_rows][55]: wires 80..134 of every PoseidonGate row
+    u32 n, num_poseidon_rows;
 };
 
 // One workgroup generates one witness: ops are pre-sorted into dependency levels; every level is a parallel
@@ -333,6 +337,32 @@ __global__ __launch_bounds__(1024) void k_witness(WitnessArgs a) {
                         atomicAdd(&mult[e], 1u);
                     }
                 }
+            } else if (o.kind == p2::OP_POSEIDON) {
+                // PoseidonGenerator: one thread computes the whole row (these ops form sequential sponge chains)
+                u64 w[135];
+                const u32 row = o.a;
+                for (u32 c = 0; c < 12; c++) {
+                    w[c] = val[a.wire_slot[(size_t)c * a.n + row]];
+                    if (w[c] == UNSET) bad = 2;
+                }
+                w[p2::PG_SWAP] = val[a.wire_slot[(size_t)p2::PG_SWAP * a.n + row]];
+                if (w[p2::PG_SWAP] == UNSET) bad = 2;
+                if (!bad) {
+                    p2::poseidon_gate_witness(w);
+                    for (u32 c = p2::PG_OUT; c < 80; c++) {
+                        if (c == p2::PG_SWAP) continue;
+                        u32 sl = (u32)a.wire_slot[(size_t)c * a.n + row];
+                        u64 cur = val[sl];
+                        if (cur == UNSET)
+                            val[sl] = w[c];
+                        else if (cur != w[c])
+                            bad = 1;
+                    }
+                    u64* adv = a.advice + ((size_t)proof * a.num_poseidon_rows + o.aux) * 55;
+                    for (u32 c = 80; c < 135; c++) adv[c - 80] = w[c];
+                }
+                if (bad) atomicMax(&s_status, bad == 1 ? 3 : 2);
+                continue;
             } else {
                 u64 x = val[o.a], y = val[o.b];
                 if (x == UNSET || y == UNSET)
@@ -371,6 +401,17 @@ __global__ void k_fill_wires(const int32_t* __restrict__ wire_slot, const u64* _
         }
     }
     wires[(size_t)blockIdx.y * wires_batch_stride + idx] = v;
+}
+
+// wires 80..134: the PoseidonGate rows take their advice block, every other row is 0
+__global__ void k_fill_advice(const int32_t* __restrict__ pos_index /*[n]: advice block of the row or -1*/, const u64* __restrict__ advice, u64* __restrict__ wires,
+                              u32 n, u32 num_poseidon_rows, size_t wires_batch_stride) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)55 * n) return;
+    u32 c = (u32)(idx / n), row = (u32)(idx % n);
+    int32_t k = pos_index[row];
+    u64 v = k >= 0 ? advice[((size_t)blockIdx.y * num_poseidon_rows + k) * 55 + c] : 0;
+    wires[(size_t)blockIdx.y * wires_batch_stride + (size_t)(80 + c) * n + row] = v;
 }
 
 struct LutRowsArgs {
@@ -523,18 +564,25 @@ __global__ void k_challenger(ChalArgs a) {
 }
 
 // Proof-of-work grinding: smallest witness w such that the duplex response has >= pow_bits leading zeros.
-// grid.y workgroups of 256 candidates each per proof (grid.x); a workgroup whose whole range lies above the
-// best witness found so far exits at once.
+// grid = (proofs, POW_BLOCKS) workgroups of 256 threads; workgroup y scans candidate blocks y, y + POW_BLOCKS, ... (256
+// candidates each) and stops as soon as the best witness found so far lies below its next block -- every wave reaches
+// that exit (or the iteration cap), so the grid always drains.  Expected work: ~2^pow_bits permutations per proof.
+static const u32 POW_BLOCKS = 64;
+static const u32 POW_MAX_ITERS = 1u << 10;  // 64 * 256 * 1024 = 2^24 candidates per proof: P(miss) = exp(-256)
 __global__ __launch_bounds__(256) void k_pow(const ChalState* st, u64* chal, int pow_bits, unsigned long long* best /*[batch]*/) {
-    const u32 p = blockIdx.x;  // proofs vary fastest: resident workgroups share the low candidate ranges of all proofs
-    u64 cand = (u64)blockIdx.y * blockDim.x + threadIdx.x;
-    unsigned long long cur = *((volatile unsigned long long*)&best[p]);
-    if (cur < (u64)blockIdx.y * blockDim.x) return;
-    DevChallenger c;
-    c.s = st[p];
-    c.observe(cand);
-    u64 resp = c.challenge();
-    if ((resp >> (64 - pow_bits)) == 0) atomicMin(&best[p], (unsigned long long)cand);
+    const u32 p = blockIdx.x;
+    DevChallenger base;
+    base.s = st[p];
+    for (u32 it = 0; it < POW_MAX_ITERS; it++) {
+        const u64 block_start = ((u64)it * POW_BLOCKS + blockIdx.y) * blockDim.x;
+        unsigned long long cur = __hip_atomic_load(&best[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur < block_start) return;  // wave-uniform: a smaller witness already exists
+        DevChallenger c = base;
+        const u64 cand = block_start + threadIdx.x;
+        c.observe(cand);
+        u64 resp = c.challenge();
+        if ((resp >> (64 - pow_bits)) == 0) atomicMin(&best[p], (unsigned long long)cand);
+    }
 }
 __global__ void k_pow_finish(u64* chal, const unsigned long long* best, u32 batch, int* status) {
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;

@@ -46,6 +46,7 @@ struct AlphaAcc {
 
 // One thread per point of the LDE coset (bit-reversed position p); evaluates every constraint of
 // eval_vanishing_poly_base, folds them with both alphas and divides by Z_H.
+template <bool HAS_POSEIDON>
 __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
     const u32 N = a.n << a.rate_bits;
     const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,10 +134,10 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
     {
         const u64* gc = C + (size_t)(a.nsel + a.nls) * N;
         const u64 c0 = gc[0], c1 = gc[(size_t)1 * N];
-        u64 f_arith = 0, f_const = 0, f_pi = 0;
+        u64 f_arith = 0, f_const = 0, f_pi = 0, f_pos = 0;
         for (u32 g = 0; g < a.num_gates; g++) {
             u32 kind = a.gate_kind[g];
-            if (kind != p2::G_ARITHMETIC && kind != p2::G_CONSTANT && kind != p2::G_PUBLIC_INPUT) continue;
+            if (kind != p2::G_ARITHMETIC && kind != p2::G_CONSTANT && kind != p2::G_PUBLIC_INPUT && kind != p2::G_POSEIDON) continue;
             u64 s = C[(size_t)a.gate_sel[g] * N], filter = 1;
             for (u32 j = a.group_lo[g]; j < a.group_hi[g]; j++)
                 if (j != g) filter = gl::mul(filter, gl::sub(j, s));
@@ -144,8 +145,10 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
             if (kind == p2::G_ARITHMETIC) f_arith = filter;
             if (kind == p2::G_CONSTANT) f_const = filter;
             if (kind == p2::G_PUBLIC_INPUT) f_pi = filter;
+            if (kind == p2::G_POSEIDON) f_pos = filter;
         }
-        for (u32 k = 0; k < a.num_gate_constraints; k++) {
+        // k-th constraint of every gate other than PoseidonGate, already multiplied by the gate's filter
+        auto other_gates = [&](u32 k) -> u64 {
             u64 term = 0;
             if (k < p2::ARITH_OPS && f_arith) {
                 u64 m0 = W[(size_t)(4 * k) * N], m1 = W[(size_t)(4 * k + 1) * N], ad = W[(size_t)(4 * k + 2) * N], o = W[(size_t)(4 * k + 3) * N];
@@ -153,7 +156,13 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
             }
             if (k < 2 && f_const) term = gl::add(term, gl::mul(f_const, gl::sub(k == 0 ? c0 : c1, W[(size_t)k * N])));
             if (k < 4 && f_pi) term = gl::add(term, gl::mul(f_pi, W[(size_t)k * N]));
-            A.push_both(term);
+            return term;
+        };
+        if (HAS_POSEIDON) {
+            p2::poseidon_gate_constraints<p2::FBase>([&](u32 i) { return W[(size_t)i * N]; },
+                                                     [&](int k, u64 cst) { A.push_both(gl::add(gl::mul(f_pos, cst), other_gates((u32)k))); });
+        } else {
+            for (u32 k = 0; k < a.num_gate_constraints; k++) A.push_both(other_gates(k));
         }
     }
     const u64 zi = a.zh_inv[coset];

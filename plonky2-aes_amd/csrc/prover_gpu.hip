@@ -36,6 +36,7 @@ struct Workspace {
     u64* d_values = nullptr;
     u32* d_mult = nullptr;
     int* d_status = nullptr;
+    u64* d_advice = nullptr;
     u64 *d_wires = nullptr, *d_wcoef = nullptr, *d_wlde = nullptr;
     u64 *d_zs = nullptr, *d_zcoef = nullptr, *d_zlde = nullptr, *d_permq = nullptr, *d_lktmp = nullptr;
     u64 *d_qvals = nullptr, *d_qres = nullptr, *d_qcoef = nullptr, *d_qlde = nullptr;
@@ -66,6 +67,7 @@ struct p2_circuit {
     int32_t *d_wire_slot = nullptr, *d_lut_idx = nullptr;
     u32 *d_lut_pairs = nullptr, *d_lut_offsets = nullptr, *d_num_lookups = nullptr;
     LookupRows* d_lookup_rows = nullptr;
+    int32_t* d_pos_index = nullptr;  // [n] advice block of a PoseidonGate row, else -1
     size_t total_lut_entries = 0;
     u64 *d_sigmas = nullptr, *d_k_is = nullptr, *d_subgroup = nullptr;
     u64 *d_tw_fwd = nullptr, *d_tw_inv = nullptr;  // w^k / w^-k for k < n_max/2, n_max = n
@@ -292,6 +294,11 @@ static int circuit_setup(p2_circuit* C) {
         if (upload(C, &C->d_num_lookups, c.num_lookups.data(), c.num_lookups.size())) return P2_ERR_HIP;
         if (upload(C, &C->d_lookup_rows, c.lookup_rows.data(), c.lookup_rows.size())) return P2_ERR_HIP;
     }
+    {
+        std::vector<int32_t> pi(n, -1);
+        for (size_t k = 0; k < c.poseidon_rows.size(); k++) pi[c.poseidon_rows[k]] = (int32_t)k;
+        if (upload(C, &C->d_pos_index, pi.data(), n)) return P2_ERR_HIP;
+    }
     if (upload(C, &C->d_sigmas, c.sigmas.data(), c.sigmas.size())) return P2_ERR_HIP;
     if (upload(C, &C->d_k_is, c.k_is.data(), c.k_is.size())) return P2_ERR_HIP;
     // twiddles, subgroup, coset tables (host-computed once; O(n) field ops)
@@ -450,6 +457,7 @@ static int alloc_workspace(p2_circuit* C, size_t chunk, u32 n_inputs, size_t nst
     e |= dalloc(C, &C->cur->d_values, chunk * c.num_slots);
     e |= dalloc(C, &C->cur->d_mult, chunk * std::max<size_t>(C->total_lut_entries, 1));
     e |= dalloc(C, &C->cur->d_status, chunk);
+    e |= dalloc(C, &C->cur->d_advice, chunk * std::max<size_t>(c.poseidon_rows.size(), 1) * 55);
     e |= dalloc(C, &C->cur->d_wires, chunk * act * n);
     e |= dalloc(C, &C->cur->d_wcoef, chunk * act * n);
     e |= dalloc(C, &C->cur->d_wlde, chunk * act * N);
@@ -519,10 +527,17 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         a.mult = C->cur->d_mult;
         a.total_lut_entries = C->total_lut_entries;
         a.status = C->cur->d_status;
+        a.wire_slot = C->d_wire_slot;
+        a.advice = C->cur->d_advice;
+        a.n = (u32)n;
+        a.num_poseidon_rows = (u32)c.poseidon_rows.size();
         LAUNCH(C, "witness", k_witness, dim3(B), dim3(1024), 0, a);
     }
     LAUNCH(C, "fill_wires", k_fill_wires, g1((size_t)R * n, 256, B), dim3(256), 0, C->d_wire_slot, C->cur->d_values, C->cur->d_wires, (size_t)R * n, c.num_slots, ws,
            C->cur->d_status);
+    if (act > R)
+        LAUNCH(C, "fill_advice", k_fill_advice, g1((size_t)55 * n, 256, B), dim3(256), 0, C->d_pos_index, C->cur->d_advice, C->cur->d_wires, (u32)n,
+               (u32)c.poseidon_rows.size(), ws);
     if (!c.luts.empty()) {
         LutRowsArgs a{};
         a.lut_pairs = C->d_lut_pairs;
@@ -614,7 +629,10 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         for (u32 l = 0; l < c.luts.size(); l++) a.lut_last_row[l] = c.lookup_rows[l].last_lut;
         a.zs_values = C->cur->d_zs;
         a.zs_values_batch_stride = zs_s;
-        LAUNCH(C, "quotient", k_quotient, g1(N, 256, B), dim3(256), 0, a);
+        if (c.poseidon_rows.empty())
+            LAUNCH(C, "quotient", k_quotient<false>, g1(N, 256, B), dim3(256), 0, a);
+        else
+            LAUNCH(C, "quotient", k_quotient<true>, g1(N, 256, B), dim3(256), 0, a);
         // coset-wise inverse transform: residues r_j, then the 8-point cross-coset DFT
         if (C->logn > LDS_NTT_MAX_BITS) {
             const size_t qs = (size_t)NC * N;
@@ -696,7 +714,7 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         if (challenger(C, 5, C->cur->d_obs, (size_t)2 * C->n_obs, (u32)(2 * fl), 0, 0, B)) return P2_ERR_HIP;
         // proof of work
         HIPCHECK(hipMemsetAsync(C->cur->d_pow_best, 0xFF, (size_t)B * 8, st));
-        LAUNCH(C, "pow", k_pow, dim3(B, 1u << 14), dim3(256), 0, C->cur->d_chal_state, C->cur->d_chal, (int)c.cfg.pow_bits, C->cur->d_pow_best);
+        LAUNCH(C, "pow", k_pow, dim3(B, POW_BLOCKS), dim3(256), 0, C->cur->d_chal_state, C->cur->d_chal, (int)c.cfg.pow_bits, C->cur->d_pow_best);
         LAUNCH(C, "pow_finish", k_pow_finish, g1(B, 64), dim3(64), 0, C->cur->d_chal, C->cur->d_pow_best, B, C->cur->d_status);
         if (challenger(C, 6, C->cur->d_obs, 0, 0, c.cfg.num_query_rounds, (u64)N, B)) return P2_ERR_HIP;
         // 10. proof assembly
@@ -813,7 +831,8 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
         C->lde_bits = c.degree_bits + c.cfg.rate_bits;
         C->N = C->n << c.cfg.rate_bits;
         C->arities = c.reduction_arity_bits();
-        C->active_wires = c.cfg.num_routed_wires;  // the gates of these circuits use routed wires only; the rest are 0
+        // routed-only gates leave wires 80..134 identically zero (never materialised); PoseidonGate rows use all 135
+        C->active_wires = c.poseidon_rows.empty() ? c.cfg.num_routed_wires : c.cfg.num_wires;
         C->pbytes = proof_bytes(c);
         if (hipSetDevice(device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
         if (hipStreamCreate(&C->stream) != hipSuccess) throw std::runtime_error("hipStreamCreate failed");

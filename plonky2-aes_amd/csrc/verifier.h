@@ -8,6 +8,7 @@
 
 #include "circuit.h"
 #include "gl.h"
+#include "poseidon_gate.h"
 
 namespace p2 {
 
@@ -313,6 +314,9 @@ inline std::string verify_proof(const Circuit& C, const VerifierData& vd, const 
                 for (int k = 0; k < 2; k++) gate[k] = add(gate[k], mul(filter, sub(gc[k], o_wires[k])));
             } else if (kind == G_PUBLIC_INPUT) {
                 for (int k = 0; k < 4; k++) gate[k] = add(gate[k], mul(filter, o_wires[k]));
+            } else if (kind == G_POSEIDON) {
+                poseidon_gate_constraints<FExt>([&](u32 i) { return o_wires[i]; },
+                                                [&](int k, E2 cst) { gate[k] = add(gate[k], mul(filter, cst)); });
             }
         }
         for (auto* v : {&z1, &ppt, &lkt, &gate}) terms.insert(terms.end(), v->begin(), v->end());

@@ -233,3 +233,48 @@ def encrypt(pkg, nk, L, tag, keys=None):  # circuit_gcm.rs:695 test_encrypt (key
 def random_states(seed, count):
     r = random.Random(seed)
     return [[r.randrange(256) for _ in range(16)] for _ in range(count)]
+
+
+def arithmetic_only(pkg, inputs):
+    """No lookup tables at all (the shape of the feistel / ecgfp5 arithmetic): mul_const_add, add, mul, sub, select,
+    is_equal and a connect between two computed values.  out = (x*y + 7*z == w) ? x + y : x*z"""
+    P = 0xFFFFFFFF00000001
+    b = pkg.CircuitBuilder()
+    x, y, z, w = (b.add_virtual_target() for _ in range(4))
+    xy = b.mul(x, y)
+    t = b.mul_const_add(7, z, xy)
+    eq = b.is_equal(t, w)
+    out = b.select(eq, b.add(x, y), b.mul(x, z))
+    t2 = b.add(b.mul_const_add(7, z, b.mul(y, x)), b.zero())   # y*x is a different op than x*y; tie the two results together
+    b.connect(t, t2)
+    data = b.build()
+    pws = []
+    for (xv, yv, zv, wv) in inputs:
+        tv = (xv * yv + 7 * zv) % P
+        pw = pkg.PartialWitness()
+        for tt, vv in ((x, xv), (y, yv), (z, zv), (w, wv), (out, (xv + yv) % P if tv == wv else xv * zv % P)):
+            pw.set_target(tt, vv % P)
+        pws.append(pw)
+    return data, pws
+
+
+def poseidon_encrypt(pkg, L, seeds):
+    """poseidon-cipher/src/circuit.rs:156-190 test body: random key point coordinates (x, u), message of L Fq elements,
+    two nonce elements; expected ciphertext from the native cipher.  (Key generation is pod2 EC arithmetic -- out of scope;
+    the shared-secret point is taken as two arbitrary Fq coordinates.)"""
+    P = 0xFFFFFFFF00000001
+    b = pkg.CircuitBuilder()
+    t = pkg.PoseidonEncryptTarget.build(b, L)
+    data = b.build()
+    pws, cases = [], []
+    for seed in seeds:
+        r = random.Random(seed)
+        fq = lambda: tuple(r.randrange(P) for _ in range(5))  # noqa: E731
+        ks, nonce, msg = [fq(), fq()], [r.randrange(P), r.randrange(P)], [fq() for _ in range(L)]
+        ct = pkg.poseidon_native.encrypt(ks, msg, nonce)
+        assert pkg.poseidon_native.decrypt(ks, ct, nonce, L) == msg
+        pw = pkg.PartialWitness()
+        t.set_targets(pw, ks, msg, nonce, ct)
+        pws.append(pw)
+        cases.append((ks, msg, nonce, ct))
+    return data, pws, t, cases

@@ -163,6 +163,27 @@ def test_reference_circuit_tests_bit_exact(gpu, orc, name):
     _gpu_vs_oracle(gpu, orc, data, pws[:2])
 
 
+def test_circuit_without_lookup_tables(gpu, orc):
+    P = 0xFFFFFFFF00000001
+    data, pws = circuits.arithmetic_only(gpu, [(3, 5, 11, 92), (3, 5, 11, 93), (P - 1, P - 2, 12345678901234567, 1)])
+    assert data.info["num_luts"] == 0
+    _gpu_vs_oracle(gpu, orc, data, pws)
+
+
+def test_poseidon_cipher_circuit(gpu, orc):
+    """poseidon-cipher (BASELINE.json configs[0] shape, L = 3 Fq = a 32-byte message; and the test's L = 129):
+    PoseidonGate rows, all 135 wire columns live, two selector groups."""
+    for L in (3, 129):
+        data, pws, t, cases = circuits.poseidon_encrypt(gpu, L, [11, 12, 13])
+        proofs, status = _gpu_vs_oracle(gpu, orc, data, pws)
+        assert status == [0, 0, 0]
+        ks, msg, nonce, ct = cases[0]
+        bad_ct = [tuple(v ^ (1 if (i, j) == (L, 4) else 0) for j, v in enumerate(fq)) for i, fq in enumerate(ct)]
+        pw = gpu.PartialWitness()
+        t.set_targets(pw, ks, msg, nonce, bad_ct)
+        assert data.prove_batch([pw])[1] == [1]
+
+
 def test_two_pass_ntt_circuit_2_15_rows(gpu, orc):
     """A circuit above 2^14 rows (AES-GCM-128 with tag, L = 256 -> n = 2^15): every NTT takes the two-pass path."""
     data, pws, _ = circuits.encrypt(gpu, 4, 256, True)

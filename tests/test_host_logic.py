@@ -200,3 +200,67 @@ def test_oracle_proofs_are_deterministic(pkg, orc):
     oc = orc.OracleCircuit(data.blob)
     a, b = oc.prove(pws[0].map)[1], oc.prove(pws[0].map)[1]
     assert a == b and hashlib.sha256(a).hexdigest() == hashlib.sha256(b).hexdigest()
+
+
+def test_circuit_without_lookup_tables(pkg, orc):
+    P = 0xFFFFFFFF00000001
+    data, pws = circuits.arithmetic_only(pkg, [(3, 5, 11, 92), (3, 5, 11, 93), (P - 1, P - 2, 12345678901234567, 1)])
+    assert data.info["num_luts"] == 0 and data.info["num_zs_cols"] == 20
+    _prove_verify(pkg, orc, data, pws)
+    bad = dict(pws[0].map)
+    bad[list(bad)[-1]] = 1
+    assert orc.OracleCircuit(data.blob).prove(bad)[0] == 1
+
+
+def test_poseidon_native_round_trip_and_sponge(pkg, orc):
+    # poseidon-cipher/src/lib.rs:127 test_encrypt_decrypt message lengths
+    import ctypes as C
+    import random
+    P = 0xFFFFFFFF00000001
+    r = random.Random(8)
+    fq = lambda: tuple(r.randrange(P) for _ in range(5))  # noqa: E731
+    for n in (9, 10, 11, 12, 128, 129, 1023, 1024, 1025):
+        ks, nonce, msg = [fq(), fq()], [r.randrange(P), r.randrange(P)], [fq() for _ in range(n)]
+        ct = pkg.poseidon_native.encrypt(ks, msg, nonce)
+        assert len(ct) == (n + 2) // 3 * 3 + 1
+        assert pkg.poseidon_native.decrypt(ks, ct, nonce, n) == msg
+        bad = list(ct)
+        bad[-1] = tuple((v + 1) % P for v in bad[-1])
+        with pytest.raises(pkg.P2Error):
+            pkg.poseidon_native.decrypt(ks, bad, nonce, n)
+    # native sponge == the oracle's hash_n_to_hash_no_pad on the first 4 outputs
+    for n in (1, 7, 8, 9, 20):
+        inp = [r.randrange(P) for _ in range(n)]
+        out = (C.c_uint64 * 4)()
+        orc.lib().orc_hash_no_pad((C.c_uint64 * n)(*inp), n, out)
+        assert pkg.poseidon_native.hash_n_to_m_no_pad(inp, 20)[:4] == list(out)
+
+
+def test_poseidon_cipher_circuit(pkg, orc):
+    # BASELINE.json configs[0] shape: 32-byte message = 3 Fq elements (L = 3); also L = 6
+    for L in (3, 6):
+        data, pws, t, cases = circuits.poseidon_encrypt(pkg, L, [1, 2])
+        assert data.info["num_luts"] == 0 and data.info["num_ops"] >= 10 * (L // 3 + 1)
+        oc, vd, res = _prove_verify(pkg, orc, data, pws)
+        ks, msg, nonce, ct = cases[0]
+        bad_ct = [tuple(v ^ (1 if (i, j) == (1, 2) else 0) for j, v in enumerate(fq)) for i, fq in enumerate(ct)]
+        pw = pkg.PartialWitness()
+        t.set_targets(pw, ks, msg, nonce, bad_ct)
+        assert oc.prove(pw.map)[0] == 1
+
+
+def test_in_circuit_hash_matches_native(pkg, orc):
+    P = 0xFFFFFFFF00000001
+    b = pkg.CircuitBuilder()
+    ins = b.add_virtual_target_arr(11)
+    outs = b.hash_n_to_m_no_pad(ins, 9)
+    data = b.build()
+    vals = [(i * 0x9E3779B97F4A7C15 + 5) % P for i in range(11)]
+    pw = pkg.PartialWitness()
+    pw.set_target_arr(ins, vals)
+    pw.set_target_arr(outs, pkg.poseidon_native.hash_n_to_m_no_pad(vals, 9))
+    _prove_verify(pkg, orc, data, [pw])
+    pw2 = pkg.PartialWitness()
+    pw2.set_target_arr(ins, vals)
+    pw2.set_target_arr(outs, [1] * 9)
+    assert orc.OracleCircuit(data.blob).prove(pw2.map)[0] == 1
