@@ -15,7 +15,7 @@ struct QuotientArgs {
     const u64* l0;      // [8n] L_0(x)
     const u64* zh_inv;  // [8] indexed by coset j
     const u64* k_is;
-    const u64* lut_polys_rows;  // unused
+    const u64* apow;  // [batch][2][APOW_STRIDE] alpha powers
     u64* out;                   // [batch][NC][8n]
     size_t out_batch_stride;
     u32 n, logn, rate_bits, R, ncc, nsel, nls, NC, npp, qdf, num_luts, nsldc, lut_deg, nlp;
@@ -26,26 +26,41 @@ struct QuotientArgs {
     size_t zs_values_batch_stride;
 };
 
+// alpha^k for k < count, per proof and challenge: apow[(proof*2 + i)*APOW_STRIDE + k]
+static const u32 APOW_STRIDE = 256;
+__global__ void k_alpha_pows(const u64* chal, u64* apow, u32 batch, u32 count) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * batch) return;
+    u64 alpha = chal[(size_t)(t >> 1) * CH_WORDS + CH_ALPHAS + (t & 1)];
+    u64* o = apow + (size_t)t * APOW_STRIDE;
+    u64 p = 1;
+    for (u32 k = 0; k < count; k++) {
+        o[k] = p;
+        p = gl::mul(p, alpha);
+    }
+}
+
+// sum_k term_k * alpha_i^k for both challenges, accumulated lazily (one reduction at the very end)
 struct AlphaAcc {
-    u64 acc[2], pw[2], alpha[2];
-    __device__ __forceinline__ void init(u64 a0, u64 a1) {
-        alpha[0] = a0;
-        alpha[1] = a1;
-        acc[0] = acc[1] = 0;
-        pw[0] = pw[1] = 1;
+    glf::Acc acc[2];
+    const u64* pw[2];
+    __device__ __forceinline__ void init(const u64* apow_proof) {
+        acc[0].init();
+        acc[1].init();
+        pw[0] = apow_proof;
+        pw[1] = apow_proof + APOW_STRIDE;
     }
-    __device__ __forceinline__ void push(int i, u64 term) {  // term for challenge-independent position, alpha i
-        acc[i] = gl::add(acc[i], gl::mul(term, pw[i]));
-        pw[i] = gl::mul(pw[i], alpha[i]);
-    }
-    __device__ __forceinline__ void push_both(u64 term) {
-        push(0, term);
-        push(1, term);
+    __device__ __forceinline__ void add(u32 idx, u64 term) {
+        acc[0].fma(term, pw[0][idx]);
+        acc[1].fma(term, pw[1][idx]);
     }
 };
 
 // One thread per point of the LDE coset (bit-reversed position p); evaluates every constraint of
-// eval_vanishing_poly_base, folds them with both alphas and divides by Z_H.
+// eval_vanishing_poly_base (term k is weighted by alpha^k, k in plonky2's order [Z(1) | partial products | lookups |
+// gates]) for both challenges at once and divides by Z_H.  Every wire / sigma value is loaded once per view
+// (permutation argument, LookupTableGate view, LookupGate view, gate constraints): the first version re-read the
+// columns per challenge and per constraint family and fetched 3.8x its algorithmic bytes (profiles/r01_traffic.json).
 template <bool HAS_POSEIDON>
 __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
     const u32 N = a.n << a.rate_bits;
@@ -64,69 +79,103 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
     const u64* S = a.pre_lde + (size_t)a.ncc * N + p;
     const u64 x = a.xs[p], l0 = a.l0[p];
     AlphaAcc A;
-    A.init(cw[CH_ALPHAS], cw[CH_ALPHAS + 1]);
-    // plonky2 orders the terms [z1 (NC), partial products (NC*(npp+1)), lookups (NC*..), gates]; the position of a
-    // term fixes its alpha power, so walk them in exactly that order.
-    for (u32 i = 0; i < a.NC; i++) A.push_both(gl::mul(l0, gl::sub(Zs[(size_t)i * N], 1)));
-    for (u32 i = 0; i < a.NC; i++) {
-        const u64 beta = cw[CH_BETAS + i], gamma = cw[CH_GAMMAS + i];
-        const u64 bx = gl::mul(beta, x);
+    A.init(a.apow + (size_t)blockIdx.y * 2 * APOW_STRIDE);
+    // term index bases
+    const u32 idx_pp = a.NC, nlk = a.nlp ? 4 + a.num_luts + 2 * a.nsldc : 0;
+    const u32 idx_lk = idx_pp + a.NC * (a.npp + 1), idx_gate = idx_lk + a.NC * nlk;
+    for (u32 i = 0; i < a.NC; i++) A.add(i, gl::mul(l0, gl::sub(Zs[(size_t)i * N], 1)));
+    {  // permutation argument, both challenges per loaded wire
+        const u64 b0 = cw[CH_BETAS], b1 = cw[CH_BETAS + 1], g0 = cw[CH_GAMMAS], g1 = cw[CH_GAMMAS + 1];
+        const u64 bx0 = gl::mul(b0, x), bx1 = gl::mul(b1, x);
         for (u32 chunk = 0; chunk <= a.npp; chunk++) {
-            u64 num = 1, den = 1;
+            u64 num0 = 1, den0 = 1, num1 = 1, den1 = 1;
             u32 j1 = min(a.R, (chunk + 1) * a.qdf);
             for (u32 j = chunk * a.qdf; j < j1; j++) {
-                u64 wv = W[(size_t)j * N];
-                num = gl::mul(num, gl::add(gl::add(wv, gl::mul(bx, a.k_is[j])), gamma));
-                den = gl::mul(den, gl::add(gl::add(wv, gl::mul(beta, S[(size_t)j * N])), gamma));
+                const u64 wv = W[(size_t)j * N], sg = S[(size_t)j * N], kj = a.k_is[j];
+                num0 = gl::mul(num0, gl::add(gl::add(wv, gl::mul(bx0, kj)), g0));
+                den0 = gl::mul(den0, gl::add(gl::add(wv, gl::mul(b0, sg)), g0));
+                num1 = gl::mul(num1, gl::add(gl::add(wv, gl::mul(bx1, kj)), g1));
+                den1 = gl::mul(den1, gl::add(gl::add(wv, gl::mul(b1, sg)), g1));
             }
-            u64 prev = chunk == 0 ? Zs[(size_t)i * N] : Zs[(size_t)(a.NC + i * a.npp + chunk - 1) * N];
-            u64 next = chunk == a.npp ? Zn[(size_t)i * N] : Zs[(size_t)(a.NC + i * a.npp + chunk) * N];
-            A.push_both(gl::sub(gl::mul(prev, num), gl::mul(next, den)));
+            for (u32 i = 0; i < 2; i++) {
+                u64 prev = chunk == 0 ? Zs[(size_t)i * N] : Zs[(size_t)(a.NC + i * a.npp + chunk - 1) * N];
+                u64 next = chunk == a.npp ? Zn[(size_t)i * N] : Zs[(size_t)(a.NC + i * a.npp + chunk) * N];
+                A.add(idx_pp + i * (a.npp + 1) + chunk, gl::sub(gl::mul(prev, i ? num1 : num0), gl::mul(next, i ? den1 : den0)));
+            }
         }
     }
     if (a.nlp) {
         const u64* sel = C + (size_t)a.nsel * N;  // TransSre, TransLdc, InitSre, LastLdc, StartEnd..
         const u64 s_sre = sel[0], s_ldc = sel[(size_t)1 * N], s_init = sel[(size_t)2 * N], s_last = sel[(size_t)3 * N];
         const u32 lk0 = a.NC * (1 + a.npp);
-        for (u32 i = 0; i < a.NC; i++) {
+        const u64 *lz[2], *lzn[2];
+        u64 dA[2], dB[2], dAl[2], dD[2], cur[2];
+        for (u32 i = 0; i < 2; i++) {
             const u64* d = cw + CH_DELTAS + 4 * i;
-            const u64 dA = d[0], dB = d[1], dAl = d[2], dD = d[3];
-            const u64* lz = Zs + (size_t)(lk0 + i * a.nlp) * N;
-            const u64* lzn = Zn + (size_t)(lk0 + i * a.nlp) * N;
-            const u64 z_re = lz[0], next_z_re = lzn[0];
-            A.push_both(gl::mul(s_last, lz[(size_t)a.nsldc * N]));
-            A.push_both(gl::mul(s_init, lz[(size_t)1 * N]));
-            A.push_both(gl::mul(s_init, z_re));
+            dA[i] = d[0];
+            dB[i] = d[1];
+            dAl[i] = d[2];
+            dD[i] = d[3];
+            lz[i] = Zs + (size_t)(lk0 + i * a.nlp) * N;
+            lzn[i] = Zn + (size_t)(lk0 + i * a.nlp) * N;
+            const u64 z_re = lz[i][0];
+            const u32 t0 = idx_lk + i * nlk;
+            A.add(t0 + 0, gl::mul(s_last, lz[i][(size_t)a.nsldc * N]));
+            A.add(t0 + 1, gl::mul(s_init, lz[i][(size_t)1 * N]));
+            A.add(t0 + 2, gl::mul(s_init, z_re));
             const u64* zv = a.zs_values + (size_t)blockIdx.y * a.zs_values_batch_stride + (size_t)(lk0 + i * a.nlp) * a.n;
-            for (u32 l = 0; l < a.num_luts; l++) A.push_both(gl::mul(sel[(size_t)(4 + l) * N], gl::sub(z_re, zv[a.lut_last_row[l]])));
-            u64 cur = next_z_re;
-            for (u32 s = 0; s < p2::LUT_SLOTS; s++) cur = gl::add(gl::mul(cur, dD), gl::add(W[(size_t)(3 * s) * N], gl::mul(dB, W[(size_t)(3 * s + 1) * N])));
-            A.push_both(gl::mul(s_sre, gl::sub(z_re, cur)));
-            for (u32 poly = 0; poly < a.nsldc; poly++) {
-                // f_k = alpha - combo_k for this poly's slots; prod = prod f_k, sum = sum_k (c_k) prod_{m != k} f_m
-                u64 f[8], mlt[8];
-                u32 a0 = poly * a.lut_deg, a1 = min(p2::LUT_SLOTS, (poly + 1) * a.lut_deg), cnt = a1 - a0;
-                for (u32 k = 0; k < cnt; k++) {
-                    u32 s = a0 + k;
-                    f[k] = gl::sub(dAl, gl::add(W[(size_t)(3 * s) * N], gl::mul(dA, W[(size_t)(3 * s + 1) * N])));
-                    mlt[k] = W[(size_t)(3 * s + 2) * N];
+            for (u32 l = 0; l < a.num_luts; l++) A.add(t0 + 3 + l, gl::mul(sel[(size_t)(4 + l) * N], gl::sub(z_re, zv[a.lut_last_row[l]])));
+            cur[i] = lzn[i][0];
+        }
+        // LookupTableGate view: slots (inp, out, mult); RE Horner and the Sum transition of each partial poly
+        {
+            u64 prod[2] = {1, 1}, sum[2] = {0, 0};
+            u32 poly = 0, in_poly = 0;
+            for (u32 s_ = 0; s_ < p2::LUT_SLOTS; s_++) {
+                const u64 win = W[(size_t)(3 * s_) * N], wout = W[(size_t)(3 * s_ + 1) * N], wm = W[(size_t)(3 * s_ + 2) * N];
+                for (u32 i = 0; i < 2; i++) {
+                    cur[i] = gl::add(gl::mul(cur[i], dD[i]), gl::add(win, gl::mul(dB[i], wout)));
+                    const u64 f = gl::sub(dAl[i], gl::add(win, gl::mul(dA[i], wout)));
+                    sum[i] = gl::add(gl::mul(sum[i], f), gl::mul(wm, prod[i]));  // sum' = sum*f + mult*prod
+                    prod[i] = gl::mul(prod[i], f);
                 }
-                u64 lut_prod = 1, lut_sum = 0;
-                for (u32 k = 0; k < cnt; k++) {  // incremental: sum' = sum*f_k + c_k*prod ; prod' = prod*f_k
-                    lut_sum = gl::add(gl::mul(lut_sum, f[k]), gl::mul(mlt[k], lut_prod));
-                    lut_prod = gl::mul(lut_prod, f[k]);
+                if (++in_poly == a.lut_deg || s_ + 1 == p2::LUT_SLOTS) {
+                    for (u32 i = 0; i < 2; i++) {
+                        u64 prev = poly == 0 ? lzn[i][(size_t)a.nsldc * N] : lz[i][(size_t)poly * N];
+                        u64 diff = gl::sub(lz[i][(size_t)(1 + poly) * N], prev);
+                        A.add(idx_lk + i * nlk + 4 + a.num_luts + 2 * poly, gl::mul(s_sre, gl::sub(gl::mul(prod[i], diff), sum[i])));
+                        prod[i] = 1;
+                        sum[i] = 0;
+                    }
+                    poly++;
+                    in_poly = 0;
                 }
-                u32 b0 = poly * (a.qdf - 1), b1 = min(p2::LU_SLOTS, (poly + 1) * (a.qdf - 1));
-                u64 lu_prod = 1, lu_sum = 0;
-                for (u32 s = b0; s < b1; s++) {
-                    u64 fk = gl::sub(dAl, gl::add(W[(size_t)(2 * s) * N], gl::mul(dA, W[(size_t)(2 * s + 1) * N])));
-                    lu_sum = gl::add(gl::mul(lu_sum, fk), lu_prod);
-                    lu_prod = gl::mul(lu_prod, fk);
+            }
+            for (u32 i = 0; i < 2; i++) A.add(idx_lk + i * nlk + 3 + a.num_luts, gl::mul(s_sre, gl::sub(lz[i][0], cur[i])));
+        }
+        // LookupGate view: slots (inp, out); the LDC transition of each partial poly
+        {
+            u64 prod[2] = {1, 1}, sum[2] = {0, 0};
+            u32 poly = 0, in_poly = 0;
+            const u32 lu_deg = a.qdf - 1;
+            for (u32 s_ = 0; s_ < p2::LU_SLOTS; s_++) {
+                const u64 win = W[(size_t)(2 * s_) * N], wout = W[(size_t)(2 * s_ + 1) * N];
+                for (u32 i = 0; i < 2; i++) {
+                    const u64 f = gl::sub(dAl[i], gl::add(win, gl::mul(dA[i], wout)));
+                    sum[i] = gl::add(gl::mul(sum[i], f), prod[i]);
+                    prod[i] = gl::mul(prod[i], f);
                 }
-                u64 prev = poly == 0 ? lzn[(size_t)a.nsldc * N] : lz[(size_t)poly * N];
-                u64 diff = gl::sub(lz[(size_t)(1 + poly) * N], prev);
-                A.push_both(gl::mul(s_sre, gl::sub(gl::mul(lut_prod, diff), lut_sum)));
-                A.push_both(gl::mul(s_ldc, gl::add(gl::mul(lu_prod, diff), lu_sum)));
+                if (++in_poly == lu_deg || s_ + 1 == p2::LU_SLOTS) {
+                    for (u32 i = 0; i < 2; i++) {
+                        u64 prev = poly == 0 ? lzn[i][(size_t)a.nsldc * N] : lz[i][(size_t)poly * N];
+                        u64 diff = gl::sub(lz[i][(size_t)(1 + poly) * N], prev);
+                        A.add(idx_lk + i * nlk + 4 + a.num_luts + 2 * poly + 1, gl::mul(s_ldc, gl::add(gl::mul(prod[i], diff), sum[i])));
+                        prod[i] = 1;
+                        sum[i] = 0;
+                    }
+                    poly++;
+                    in_poly = 0;
+                }
             }
         }
     }
@@ -150,25 +199,27 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
         // k-th constraint of every gate other than PoseidonGate, already multiplied by the gate's filter
         auto other_gates = [&](u32 k) -> u64 {
             u64 term = 0;
+            u64 w0 = 0;
             if (k < p2::ARITH_OPS && f_arith) {
                 u64 m0 = W[(size_t)(4 * k) * N], m1 = W[(size_t)(4 * k + 1) * N], ad = W[(size_t)(4 * k + 2) * N], o = W[(size_t)(4 * k + 3) * N];
                 term = gl::mul(f_arith, gl::sub(o, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1))));
             }
-            if (k < 2 && f_const) term = gl::add(term, gl::mul(f_const, gl::sub(k == 0 ? c0 : c1, W[(size_t)k * N])));
-            if (k < 4 && f_pi) term = gl::add(term, gl::mul(f_pi, W[(size_t)k * N]));
+            if (k < 4 && (f_const || f_pi)) w0 = W[(size_t)k * N];
+            if (k < 2 && f_const) term = gl::add(term, gl::mul(f_const, gl::sub(k == 0 ? c0 : c1, w0)));
+            if (k < 4 && f_pi) term = gl::add(term, gl::mul(f_pi, w0));
             return term;
         };
         if (HAS_POSEIDON) {
             p2::poseidon_gate_constraints<p2::FBase>([&](u32 i) { return W[(size_t)i * N]; },
-                                                     [&](int k, u64 cst) { A.push_both(gl::add(gl::mul(f_pos, cst), other_gates((u32)k))); });
+                                                     [&](int k, u64 cst) { A.add(idx_gate + (u32)k, gl::add(gl::mul(f_pos, cst), other_gates((u32)k))); });
         } else {
-            for (u32 k = 0; k < a.num_gate_constraints; k++) A.push_both(other_gates(k));
+            for (u32 k = 0; k < a.num_gate_constraints; k++) A.add(idx_gate + k, other_gates(k));
         }
     }
     const u64 zi = a.zh_inv[coset];
     u64* out = a.out + (size_t)blockIdx.y * a.out_batch_stride + p;
-    out[0] = gl::mul(A.acc[0], zi);
-    out[(size_t)N] = gl::mul(A.acc[1], zi);
+    out[0] = gl::mul(A.acc[0].reduce(), zi);
+    out[(size_t)N] = gl::mul(A.acc[1].reduce(), zi);
 }
 
 // ------------------------------------------------------------------------------------------- openings

@@ -43,7 +43,7 @@ struct Workspace {
     Tree wtree, ztree, qtree;
     ChalState* d_chal_state = nullptr;
     u64* d_chal = nullptr;
-    u64 *d_pows = nullptr, *d_ev = nullptr, *d_obs = nullptr, *d_comp = nullptr;
+    u64 *d_pows = nullptr, *d_ev = nullptr, *d_obs = nullptr, *d_comp = nullptr, *d_apow = nullptr;
     u64* d_fri_coef[9] = {nullptr};  // [2][n_r]
     u64* d_fri_vals[9] = {nullptr};  // [2][8 n_r]
     Tree fri_tree[9];
@@ -480,6 +480,7 @@ static int alloc_workspace(p2_circuit* C, size_t chunk, u32 n_inputs, size_t nst
     e |= dalloc(C, &C->cur->d_ev, chunk * 2 * C->ev_count);
     e |= dalloc(C, &C->cur->d_obs, chunk * 2 * C->n_obs);
     e |= dalloc(C, &C->cur->d_comp, chunk * 4 * n);
+    e |= dalloc(C, &C->cur->d_apow, chunk * 2 * APOW_STRIDE);
     u32 logn_r = C->logn;
     for (u32 r = 0; r <= C->arities.size(); r++) {
         size_t n_r = (size_t)1 << logn_r;
@@ -629,6 +630,13 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         for (u32 l = 0; l < c.luts.size(); l++) a.lut_last_row[l] = c.lookup_rows[l].last_lut;
         a.zs_values = C->cur->d_zs;
         a.zs_values_batch_stride = zs_s;
+        a.apow = C->cur->d_apow;
+        {
+            u32 nlk = nlp ? 4 + (u32)c.luts.size() + 2 * nsldc : 0;
+            u32 nterms = NC + NC * (npp + 1) + NC * nlk + c.num_gate_constraints;
+            if (nterms > APOW_STRIDE) return set_error("internal: too many vanishing terms for the alpha-power table"), P2_ERR_INVALID;
+            LAUNCH(C, "alpha_pows", k_alpha_pows, g1(2 * B, 64), dim3(64), 0, C->cur->d_chal, C->cur->d_apow, B, nterms);
+        }
         if (c.poseidon_rows.empty())
             LAUNCH(C, "quotient", k_quotient<false>, g1(N, 256, B), dim3(256), 0, a);
         else
