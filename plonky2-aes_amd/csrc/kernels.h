@@ -146,7 +146,8 @@ __global__ __launch_bounds__(1024) void k_ntt_lds(NttArgs a) {
     }
     __syncthreads();
     const int tw_shift = a.log_nmax - logn;
-    for (int s = logn - 1; s >= 0; s--) {
+    int s = logn - 1;
+    if (logn & 1) {  // odd number of stages: one radix-2 stage first
         const u32 h = 1u << s;
         for (u32 t = threadIdx.x; t < (n >> 1); t += blockDim.x) {
             u32 pos = t & (h - 1);
@@ -155,6 +156,29 @@ __global__ __launch_bounds__(1024) void k_ntt_lds(NttArgs a) {
             u64 w = a.tw[(size_t)(pos << (logn - 1 - s)) << tw_shift];
             lds[i] = gl::add(x, y);
             lds[i + h] = gl::mul(gl::sub(x, y), w);
+        }
+        __syncthreads();
+        s--;
+    }
+    // radix-4 steps: DIF stages s and s-1 fused -- each thread owns x[i], x[i+q], x[i+h], x[i+h+q] (h = 2^s, q = h/2) for
+    // both stages, so the data crosses LDS once per two stages and the barrier count halves
+    for (; s >= 1; s -= 2) {
+        const u32 h = 1u << s, q = h >> 1;
+        for (u32 t = threadIdx.x; t < (n >> 2); t += blockDim.x) {
+            u32 pos = t & (q - 1);                       // i mod q
+            u32 i = ((t >> (s - 1)) << (s + 1)) | pos;  // bits s and s-1 of i are zero
+            u64 a0 = lds[i], a1 = lds[i + q], a2 = lds[i + h], a3 = lds[i + h + q];
+            // stage s: twiddle w_{2h}^(i mod h); here i mod h = pos and (i+q) mod h = pos + q
+            u64 w0 = a.tw[(size_t)(pos << (logn - 1 - s)) << tw_shift];
+            u64 w1 = a.tw[(size_t)((pos + q) << (logn - 1 - s)) << tw_shift];
+            u64 b0 = gl::add(a0, a2), b2 = gl::mul(gl::sub(a0, a2), w0);
+            u64 b1 = gl::add(a1, a3), b3 = gl::mul(gl::sub(a1, a3), w1);
+            // stage s-1: twiddle w_{2q}^(i mod q), the same for both pairs
+            u64 w2 = a.tw[(size_t)(pos << (logn - s)) << tw_shift];
+            lds[i] = gl::add(b0, b1);
+            lds[i + q] = gl::mul(gl::sub(b0, b1), w2);
+            lds[i + h] = gl::add(b2, b3);
+            lds[i + h + q] = gl::mul(gl::sub(b2, b3), w2);
         }
         __syncthreads();
     }
@@ -564,14 +588,14 @@ __global__ void k_challenger(ChalArgs a) {
 }
 
 // Proof-of-work grinding: smallest witness w such that the duplex response has >= pow_bits leading zeros.
-// grid = (proofs, POW_BLOCKS): one 256-candidate block per workgroup, proofs varying fastest so that the workgroups
+// grid = (proofs, POW_BLOCKS): one 1024-candidate block per workgroup, proofs varying fastest so that the workgroups
 // resident at any moment cover the low candidate ranges of every proof; a workgroup whose whole block lies above the
 // best witness found so far exits at once (the common case: ~2^pow_bits candidates are needed per proof).
 // 2^21 candidates per proof: the probability that none works is exp(-32) (reported as status 4, never a bad proof).
 // (A persistent strided loop was measured 3x slower: only half of its workgroups are resident at once and the
 // unluckiest proof of a chunk serialises ~100 us iterations.)
-static const u32 POW_BLOCKS = 1u << 13;
-__global__ __launch_bounds__(256) void k_pow(const ChalState* st, u64* chal, int pow_bits, unsigned long long* best /*[batch]*/) {
+static const u32 POW_BLOCKS = 1u << 11;  // x 1024 candidates
+__global__ __launch_bounds__(1024) void k_pow(const ChalState* st, u64* chal, int pow_bits, unsigned long long* best /*[batch]*/) {
     const u32 p = blockIdx.x;
     const u64 block_start = (u64)blockIdx.y * blockDim.x;
     unsigned long long cur = __hip_atomic_load(&best[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
