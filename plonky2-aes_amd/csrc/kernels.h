@@ -596,16 +596,29 @@ __global__ void k_challenger(ChalArgs a) {
 // unluckiest proof of a chunk serialises ~100 us iterations.)
 static const u32 POW_BLOCKS = 1u << 11;  // x 1024 candidates
 __global__ __launch_bounds__(1024) void k_pow(const ChalState* st, u64* chal, int pow_bits, unsigned long long* best /*[batch]*/) {
+    // The candidate is the next observed element: whether or not it completes the rate, the response is word 7 of
+    // permute(state overwritten by the buffered inputs and the candidate).  The overwritten state is the same for every
+    // candidate of a proof, so it is staged once per workgroup in LDS and the permutation runs entirely in registers.
+    __shared__ u64 sh[12];
+    __shared__ u32 sh_pos;
     const u32 p = blockIdx.x;
     const u64 block_start = (u64)blockIdx.y * blockDim.x;
     unsigned long long cur = __hip_atomic_load(&best[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur < block_start) return;
-    DevChallenger c;
-    c.s = st[p];
+    if (cur < block_start) return;  // workgroup-uniform
+    if (threadIdx.x < 12) {
+        const ChalState* s = st + p;
+        u32 i = threadIdx.x;
+        sh[i] = (i < s->in_len) ? s->in[i] : s->state[i];
+        if (i == 0) sh_pos = s->in_len;
+    }
+    __syncthreads();
     const u64 cand = block_start + threadIdx.x;
-    c.observe(cand);
-    u64 resp = c.challenge();
-    if ((resp >> (64 - pow_bits)) == 0) atomicMin(&best[p], (unsigned long long)cand);
+    const u32 pos = sh_pos;
+    u64 r[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) r[i] = ((u32)i == pos) ? cand : sh[i];
+    glf::poseidon(r);
+    if ((r[7] >> (64 - pow_bits)) == 0) atomicMin(&best[p], (unsigned long long)cand);
 }
 __global__ void k_pow_finish(u64* chal, const unsigned long long* best, u32 batch, int* status) {
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
