@@ -331,10 +331,31 @@ __global__ __launch_bounds__(1024) void k_witness(WitnessArgs a) {
         }
     }
     __syncthreads();
+    // The op descriptors do not depend on witness values, so each thread fetches its first descriptor of level lv+1
+    // before it starts on level lv: on deep circuits (10^4 levels, descriptors streaming from HBM) the descriptor
+    // latency is the longest link of the per-level dependency chain.
+    p2::Op nxt;
+    bool have_nxt = false;
+    u32 nbeg = a.level_offsets[0], nend = a.num_levels ? a.level_offsets[1] : nbeg;
+    if (nbeg + threadIdx.x < nend) {
+        nxt = a.ops[nbeg + threadIdx.x];
+        have_nxt = true;
+    }
     for (u32 lv = 0; lv < a.num_levels; lv++) {
-        const u32 beg = a.level_offsets[lv], end = a.level_offsets[lv + 1];
+        const u32 beg = nbeg, end = nend;
+        const p2::Op first = nxt;
+        const bool have_first = have_nxt;
+        have_nxt = false;
+        if (lv + 1 < a.num_levels) {
+            nbeg = end;
+            nend = a.level_offsets[lv + 2];
+            if (nbeg + threadIdx.x < nend) {
+                nxt = a.ops[nbeg + threadIdx.x];
+                have_nxt = true;
+            }
+        }
         for (u32 k = beg + threadIdx.x; k < end; k += blockDim.x) {
-            const p2::Op o = a.ops[k];
+            const p2::Op o = (have_first && k == beg + threadIdx.x) ? first : a.ops[k];
             u64 r = 0;
             int bad = 0;
             if (o.kind == p2::OP_ARITH) {
