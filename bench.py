@@ -162,11 +162,21 @@ def main():
             kb = kernel_bytes(dom, info)
             nbytes = kb * chunk if kb else None
         avg_ms = ms / cnt
+        traffic = None
+        try:  # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x2 per calibration, WRITE_SIZE), profiles/
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            key = {"hash_leaves": "k_hash_leaves", "lde": "k_ntt_lds", "quotient": "k_quotient<false>"}.get(dom)
+            if key and L == 1024 and chunk == 32:
+                traffic = tj["per_launch_avg_bytes"][key]["total"]
+        except Exception:  # noqa: BLE001
+            traffic = None
         if nbytes:
             ach = nbytes / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
-                        "share_of_gpu_time": round(ms / total, 3)}
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(avg_ms, 4),
+                        "share_of_gpu_time": round(ms / total, 3),
+                        "note": "kernel is VALU-issue bound (Poseidon: ~44k issue slots per permutation), not HBM bound; see DESIGN.md section 5",
+                        "poseidon_perm_per_s": round((24 * (8 << info["degree_bits"]) * chunk / 3.0) / (avg_ms * 1e-3)) if dom == "hash_leaves" else None}
 
     cpu_baseline = None
     if rank == 0 and not args.no_cpu_baseline:

@@ -609,14 +609,14 @@ __global__ void k_challenger(ChalArgs a) {
 }
 
 // Proof-of-work grinding: smallest witness w such that the duplex response has >= pow_bits leading zeros.
-// grid = (proofs, POW_BLOCKS): one 1024-candidate block per workgroup, proofs varying fastest so that the workgroups
+// grid = (proofs, POW_BLOCKS): one 256-candidate block per workgroup, proofs varying fastest so that the workgroups
 // resident at any moment cover the low candidate ranges of every proof; a workgroup whose whole block lies above the
 // best witness found so far exits at once (the common case: ~2^pow_bits candidates are needed per proof).
 // 2^21 candidates per proof: the probability that none works is exp(-32) (reported as status 4, never a bad proof).
 // (A persistent strided loop was measured 3x slower: only half of its workgroups are resident at once and the
 // unluckiest proof of a chunk serialises ~100 us iterations.)
-static const u32 POW_BLOCKS = 1u << 11;  // x 1024 candidates
-__global__ __launch_bounds__(1024) void k_pow(const ChalState* st, u64* chal, int pow_bits, unsigned long long* best /*[batch]*/) {
+static const u32 POW_BLOCKS = 1u << 13;  // x 256 candidates
+__global__ __launch_bounds__(256) void k_pow(const ChalState* st, u64* chal, int pow_bits, unsigned long long* best /*[batch]*/) {
     // The candidate is the next observed element: whether or not it completes the rate, the response is word 7 of
     // permute(state overwritten by the buffered inputs and the candidate).  The overwritten state is the same for every
     // candidate of a proof, so it is staged once per workgroup in LDS and the permutation runs entirely in registers.
@@ -624,8 +624,13 @@ __global__ __launch_bounds__(1024) void k_pow(const ChalState* st, u64* chal, in
     __shared__ u32 sh_pos;
     const u32 p = blockIdx.x;
     const u64 block_start = (u64)blockIdx.y * blockDim.x;
-    unsigned long long cur = __hip_atomic_load(&best[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur < block_start) return;  // workgroup-uniform
+    // `best` is updated by workgroups on all 8 XCDs; their L2s are not coherent with each other, so a plain (even sc1)
+    // load can keep returning this XCD's stale copy.  A no-op atomic min executes at the memory side and returns the
+    // current value; one lane per workgroup issues it.
+    __shared__ unsigned long long sh_cur;
+    if (threadIdx.x == 0) sh_cur = atomicMin(&best[p], ~0ull);
+    __syncthreads();
+    if (sh_cur < block_start) return;  // workgroup-uniform
     if (threadIdx.x < 12) {
         const ChalState* s = st + p;
         u32 i = threadIdx.x;

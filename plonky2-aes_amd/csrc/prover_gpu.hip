@@ -722,7 +722,7 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         if (challenger(C, 5, C->cur->d_obs, (size_t)2 * C->n_obs, (u32)(2 * fl), 0, 0, B)) return P2_ERR_HIP;
         // proof of work
         HIPCHECK(hipMemsetAsync(C->cur->d_pow_best, 0xFF, (size_t)B * 8, st));
-        LAUNCH(C, "pow", k_pow, dim3(B, POW_BLOCKS), dim3(1024), 0, C->cur->d_chal_state, C->cur->d_chal, (int)c.cfg.pow_bits, C->cur->d_pow_best);
+        LAUNCH(C, "pow", k_pow, dim3(B, POW_BLOCKS), dim3(256), 0, C->cur->d_chal_state, C->cur->d_chal, (int)c.cfg.pow_bits, C->cur->d_pow_best);
         LAUNCH(C, "pow_finish", k_pow_finish, g1(B, 64), dim3(64), 0, C->cur->d_chal, C->cur->d_pow_best, B, C->cur->d_status);
         if (challenger(C, 6, C->cur->d_obs, 0, 0, c.cfg.num_query_rounds, (u64)N, B)) return P2_ERR_HIP;
         // 10. proof assembly
