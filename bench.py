@@ -167,7 +167,7 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             key = {"hash_leaves": "k_hash_leaves", "lde": "k_ntt_lds", "quotient": "k_quotient<false>"}.get(dom)
             if key and L == 1024 and chunk == 32:
-                traffic = tj["per_launch_avg_bytes"][key]["total"]
+                traffic = tj["per_launch_avg_bytes"][key].get("total_chunk_launches_only", tj["per_launch_avg_bytes"][key]["total"])
         except Exception:  # noqa: BLE001
             traffic = None
         if nbytes:
