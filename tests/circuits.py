@@ -278,3 +278,49 @@ def poseidon_encrypt(pkg, L, seeds):
         pws.append(pw)
         cases.append((ks, msg, nonce, ct))
     return data, pws, t, cases
+
+
+def feistel_native(pkg, state, key_schedule, inverse=False):
+    """feistel/src/lib.rs:15-75 with f = Poseidon hash_n_to_hash_no_pad (additive Feistel network over the field)."""
+    P = 0xFFFFFFFF00000001
+    h = len(state) // 2
+    f = lambda v: pkg.poseidon_native.hash_n_to_m_no_pad(v, 4)  # noqa: E731
+    st = list(state)
+    for k in key_schedule:
+        l, r = st[:h], st[h:]
+        if not inverse:
+            off = f(r + list(k))
+            st = r + [(l[i] + off[i]) % P for i in range(h)]
+        else:
+            off = f(l + list(k))
+            st = [(r[i] - off[i]) % P for i in range(h)] + l
+    return st
+
+
+def feistel_poseidon(pkg, seeds, rounds=32):
+    """feistel/src/circuit.rs:115 feistel_poseidon_check: STATE_HALF_LEN = 4, KEY_LEN = 4, NR = 32 rounds; built from
+    the generic builder API only (hash_n_to_hash_no_pad = first 4 sponge outputs, then `add`)."""
+    P = 0xFFFFFFFF00000001
+    b = pkg.CircuitBuilder()
+    state_t = b.add_virtual_target_arr(8)
+    keys_t = [b.add_virtual_target_arr(4) for _ in range(rounds)]
+    st = list(state_t)
+    for k in keys_t:
+        l, r = st[:4], st[4:]
+        off = b.hash_n_to_m_no_pad(r + k, 4)
+        st = r + [b.add(l[i], off[i]) for i in range(4)]
+    data = b.build()
+    pws = []
+    for seed in seeds:
+        rr = random.Random(seed)
+        state = [rr.randrange(P) for _ in range(8)]
+        ks = [[rr.randrange(P) for _ in range(4)] for _ in range(rounds)]
+        out = feistel_native(pkg, state, ks)
+        assert feistel_native(pkg, out, ks[::-1], inverse=True) == state      # lib.rs:98 round trip
+        pw = pkg.PartialWitness()
+        pw.set_target_arr(state_t, state)
+        for kt, kv in zip(keys_t, ks):
+            pw.set_target_arr(kt, kv)
+        pw.set_target_arr(st, out)
+        pws.append(pw)
+    return data, pws

@@ -184,6 +184,12 @@ def test_poseidon_cipher_circuit(gpu, orc):
         assert data.prove_batch([pw])[1] == [1]
 
 
+def test_feistel_poseidon_circuit(gpu, orc):
+    # feistel/src/circuit.rs:115: 32 rounds, one PoseidonGate row + 4 additions per round
+    data, pws = circuits.feistel_poseidon(gpu, [3, 4, 5])
+    _gpu_vs_oracle(gpu, orc, data, pws)
+
+
 def test_two_pass_ntt_circuit_2_15_rows(gpu, orc):
     """A circuit above 2^14 rows (AES-GCM-128 with tag, L = 256 -> n = 2^15): every NTT takes the two-pass path."""
     data, pws, _ = circuits.encrypt(gpu, 4, 256, True)

@@ -264,3 +264,12 @@ def test_in_circuit_hash_matches_native(pkg, orc):
     pw2.set_target_arr(ins, vals)
     pw2.set_target_arr(outs, [1] * 9)
     assert orc.OracleCircuit(data.blob).prove(pw2.map)[0] == 1
+
+
+def test_feistel_poseidon_circuit(pkg, orc):
+    data, pws = circuits.feistel_poseidon(pkg, [1, 2])
+    assert data.info["num_luts"] == 0
+    oc, vd, res = _prove_verify(pkg, orc, data, pws)
+    bad = dict(pws[0].map)
+    bad[list(bad)[-1]] ^= 1
+    assert oc.prove(bad)[0] == 1
