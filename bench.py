@@ -87,7 +87,7 @@ def main():
 
     L, B = args.plaintext_bytes, args.batch
     if L > 4096 and args.batch == 64:
-        B = 8  # deep circuits: a proof is ~32x the work and ~7 GB of workspace
+        B = 16  # deep circuits: ~7 GB of workspace per proof -> two chunks of 8, one per stream, so witness generation overlaps
     builder = pkg.CircuitBuilder()
     target = pkg.AesGcmTarget.build(builder, 4, 10, L, False)  # AesGcm128Target<L>, aes-gcm/src/lib.rs:19
     data = pkg.CircuitData(builder.build().blob, device=local_rank)

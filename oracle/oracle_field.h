@@ -115,10 +115,12 @@ static inline void poseidon_permute(u64 st[12]) {
             for (int i = 0; i < 12; i++) st[i] = pow7(st[i]);
         else
             st[0] = pow7(st[0]);
-        u64 nx[12];
+        u64 twice[24], nx[12];  // state laid out twice so that the circulant rows need no index wrap
+        memcpy(twice, st, 96);
+        memcpy(twice + 12, st, 96);
         for (int r = 0; r < 12; r++) {
             u128 acc = 0;
-            for (int i = 0; i < 12; i++) acc += (u128)st[(i + r) % 12] * MDS_CIRC[i];
+            for (int i = 0; i < 12; i++) acc += (u128)twice[i + r] * MDS_CIRC[i];
             acc += (u128)st[r] * MDS_DIAG[r];
             nx[r] = fred(acc);
         }

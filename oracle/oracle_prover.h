@@ -807,12 +807,17 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
         tr("fri_final_poly", f);
     }
     // proof of work: smallest witness whose response has >= pow_bits leading zeros
-    u64 pow_witness = 0;
-    for (;; pow_witness++) {
-        Challenger c2 = chal;
-        c2.observe(pow_witness);
-        u64 resp = c2.challenge();
-        if ((resp >> (64 - C.cfg.pow_bits)) == 0) break;
+    u64 pow_witness = ~0ull;
+    for (u64 base = 0; pow_witness == ~0ull; base += 1 << 14) {  // blocks of 2^14 candidates, smallest hit of the first block with one
+        u64 found = ~0ull;
+#pragma omp parallel for schedule(static) reduction(min : found)
+        for (long long k = 0; k < (1 << 14); k++) {
+            Challenger c2 = chal;
+            c2.observe(base + (u64)k);
+            u64 resp = c2.challenge();
+            if ((resp >> (64 - C.cfg.pow_bits)) == 0 && base + (u64)k < found) found = base + (u64)k;
+        }
+        pow_witness = found;
     }
     chal.observe(pow_witness);
     (void)chal.challenge();
