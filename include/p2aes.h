@@ -158,7 +158,8 @@ typedef struct {
  * proofs are in host memory.  Safe to call concurrently on different p2_circuit handles. */
 int p2_prove_batch(p2_circuit*, size_t batch, const p2_assignment* inputs, uint8_t* proofs, int* status);
 /* Same pipeline with inputs already resident on the device and proofs left on the device:
- * d_values: [batch][n_targets] u64 (device pointer), targets shared by the whole batch (host pointer).
+ * d_values: [batch][n_targets] u64 (device pointer), targets shared by the whole batch (host pointer); the value
+ * 2^64-1 (not a field element) marks "this witness does not assign the target".
  * d_proofs: device buffer of batch * proof_bytes; d_status: device int[batch].  Asynchronous on `stream`
  * (a hipStream_t passed as void*, NULL = the circuit's own stream); used by bench.py's timed region. */
 int p2_prove_batch_device(p2_circuit*, size_t batch, const p2_target* targets, size_t n_targets, const uint64_t* d_values,

@@ -323,6 +323,7 @@ __global__ __launch_bounds__(1024) void k_witness(WitnessArgs a) {
         for (u32 i = 0; i < a.n_inputs; i++) {
             u32 s = a.input_slots[i];
             u64 v = iv[i];
+            if (v == UNSET) continue;  // this witness does not assign the target (batches share one target list)
             if (v >= gl::P) s_status = 3;
             if (val[s] == UNSET)
                 val[s] = v;

@@ -988,15 +988,35 @@ int p2_circuit_synchronize(p2_circuit* C) {
 int p2_prove_batch(p2_circuit* C, size_t batch, const p2_assignment* inputs, uint8_t* proofs, int* status) {
     if (batch == 0) return P2_OK;
     HIPCHECK(hipSetDevice(C->device));
-    // Every PartialWitness of the batch must assign the same target list (same order); duplicates are allowed.
+    // Fast path: every PartialWitness assigns the same target list in the same order.  Otherwise the batch is put on
+    // the union of the targets, a witness that does not assign a target gets the "absent" marker (2^64-1, not a field
+    // element), and a witness that assigns one target two different values fails on the host like set_target does.
     size_t nt = inputs[0].count;
-    for (size_t i = 1; i < batch; i++) {
-        if (inputs[i].count != nt || memcmp(inputs[i].targets, inputs[0].targets, nt * 8) != 0)
-            return set_error("all witnesses of a batch must assign the same targets in the same order"), P2_ERR_INVALID;
+    bool same = true;
+    for (size_t i = 1; i < batch && same; i++) same = inputs[i].count == nt && memcmp(inputs[i].targets, inputs[0].targets, nt * 8) == 0;
+    std::vector<u64> union_targets, hv;
+    std::vector<int> host_status(batch, 0);
+    const p2_target* targets = inputs[0].targets;
+    if (same) {
+        hv.resize(batch * std::max<size_t>(nt, 1));
+        for (size_t i = 0; i < batch; i++)
+            for (size_t k = 0; k < nt; k++) hv[i * nt + k] = inputs[i].values[k];
+    } else {
+        std::map<u64, size_t> col;
+        for (size_t i = 0; i < batch; i++)
+            for (size_t k = 0; k < inputs[i].count; k++)
+                if (col.emplace(inputs[i].targets[k], union_targets.size()).second) union_targets.push_back(inputs[i].targets[k]);
+        nt = union_targets.size();
+        hv.assign(batch * std::max<size_t>(nt, 1), ~0ull);
+        for (size_t i = 0; i < batch; i++)
+            for (size_t k = 0; k < inputs[i].count; k++) {
+                u64& cell = hv[i * nt + col[inputs[i].targets[k]]];
+                u64 v = inputs[i].values[k];
+                if (v >= gl::P || (cell != ~0ull && cell != v)) host_status[i] = P2_PROOF_WITNESS_CONFLICT;
+                cell = v;
+            }
+        targets = union_targets.data();
     }
-    std::vector<u64> hv(batch * std::max<size_t>(nt, 1));
-    for (size_t i = 0; i < batch; i++)
-        for (size_t k = 0; k < nt; k++) hv[i * nt + k] = inputs[i].values[k];
     u64* d_vals = nullptr;
     uint8_t* d_proofs = nullptr;
     int* d_stat = nullptr;
@@ -1004,13 +1024,18 @@ int p2_prove_batch(p2_circuit* C, size_t batch, const p2_assignment* inputs, uin
     HIPCHECK(hipMalloc((void**)&d_proofs, batch * C->pbytes));
     HIPCHECK(hipMalloc((void**)&d_stat, batch * sizeof(int)));
     HIPCHECK(hipMemcpy(d_vals, hv.data(), hv.size() * 8, hipMemcpyHostToDevice));
-    int rc = p2_prove_batch_device(C, batch, inputs[0].targets, nt, d_vals, d_proofs, d_stat, nullptr);
+    int rc = p2_prove_batch_device(C, batch, targets, nt, d_vals, d_proofs, d_stat, nullptr);
     if (rc == P2_OK) rc = p2_circuit_synchronize(C);
     if (rc == P2_OK) {
         if (hipMemcpy(proofs, d_proofs, batch * C->pbytes, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(status, d_stat, batch * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
             set_error("copying proofs back failed");
             rc = P2_ERR_HIP;
         }
+        for (size_t i = 0; i < batch && rc == P2_OK; i++)
+            if (host_status[i]) {
+                status[i] = host_status[i];
+                memset(proofs + i * C->pbytes, 0, C->pbytes);
+            }
     }
     hipFree(d_vals);
     hipFree(d_proofs);

@@ -119,6 +119,11 @@ def test_missing_and_conflicting_inputs(gpu, orc):
     missing.map = dict(pws[0].map)
     del missing.map[list(missing.map)[0]]    # an input never set -> a generator never runs
     assert data.prove_batch([missing])[1] == [2]
+    # witnesses of one batch may assign different target sets, in different orders
+    shuffled = gpu.PartialWitness()
+    shuffled.map = dict(reversed(list(pws[2].map.items())))
+    proofs3, status3 = data.prove_batch([pws[0], missing, shuffled, bad])
+    assert status3 == [0, 2, 0, 1] and proofs3[0] == proofs[0] and proofs3[2] == proofs[2]
     other = gpu.PartialWitness()
     other.set_target(10 ** 9, 1)
     with pytest.raises(gpu.P2Error):
