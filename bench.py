@@ -105,8 +105,10 @@ def main():
     status = torch.zeros(B, dtype=torch.int32, device="cuda")
     tarr = (C.c_uint64 * nt)(*targets)
 
+    torch_stream = torch.cuda.current_stream().cuda_stream  # orders the proving streams after the tensors above
+
     def step():
-        rc = lib.p2_prove_batch_device(h, B, tarr, nt, vals.data_ptr(), proofs.data_ptr(), status.data_ptr(), None)
+        rc = lib.p2_prove_batch_device(h, B, tarr, nt, vals.data_ptr(), proofs.data_ptr(), status.data_ptr(), torch_stream)
         if rc:
             raise RuntimeError(lib.p2_last_error().decode())
 
@@ -142,7 +144,7 @@ def main():
     if rank == 0:
         lib.p2_circuit_set_timing(h, 1)
         chunk = min(B, 32)
-        rc = lib.p2_prove_batch_device(h, chunk, tarr, nt, vals.data_ptr(), proofs.data_ptr(), status.data_ptr(), None)  # one chunk = one stream
+        rc = lib.p2_prove_batch_device(h, chunk, tarr, nt, vals.data_ptr(), proofs.data_ptr(), status.data_ptr(), torch_stream)  # one chunk = one stream
         assert rc == 0
         sync()
         arr = (pkg.api._KernelTime * 64)()

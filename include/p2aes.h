@@ -160,8 +160,10 @@ int p2_prove_batch(p2_circuit*, size_t batch, const p2_assignment* inputs, uint8
 /* Same pipeline with inputs already resident on the device and proofs left on the device:
  * d_values: [batch][n_targets] u64 (device pointer), targets shared by the whole batch (host pointer); the value
  * 2^64-1 (not a field element) marks "this witness does not assign the target".
- * d_proofs: device buffer of batch * proof_bytes; d_status: device int[batch].  Asynchronous on `stream`
- * (a hipStream_t passed as void*, NULL = the circuit's own stream); used by bench.py's timed region. */
+ * d_proofs: device buffer of batch * proof_bytes; d_status: device int[batch].  Asynchronous: kernels are enqueued on
+ * the circuit's own streams.  `stream` (a hipStream_t passed as void*) orders the call with the caller: the proving
+ * streams wait for the work already enqueued on it and it then waits for the proofs; with NULL the device is
+ * synchronised before proving and the caller must call p2_circuit_synchronize() before reading the outputs. */
 int p2_prove_batch_device(p2_circuit*, size_t batch, const p2_target* targets, size_t n_targets, const uint64_t* d_values,
                           uint8_t* d_proofs, int* d_status, void* stream);
 int p2_circuit_synchronize(p2_circuit*);
@@ -180,7 +182,7 @@ int p2_gpu_device_count(void);
 int p2_gpu_poseidon(uint64_t* states, size_t n_perm, int device);
 /* columns: [cols][n] coefficients (host) -> lde [cols][n<<rate_bits], bit-reversed index order (host) */
 int p2_gpu_lde(const uint64_t* coeffs, size_t cols, int degree_bits, int rate_bits, uint64_t* lde, int device);
-/* values [cols][n] -> coefficients [cols][n] */
+/* values [cols][n] -> coefficients [cols][n]; degree_bits 1..22 (above 14: two-pass transform) */
 int p2_gpu_intt(const uint64_t* values, size_t cols, int degree_bits, uint64_t* coeffs, int device);
 /* column-major leaves [cols][num_leaves] -> cap digests (2^cap_height * 4 u64) */
 int p2_gpu_merkle_cap(const uint64_t* cols_major, size_t cols, size_t num_leaves, int cap_height, uint64_t* cap, int device);

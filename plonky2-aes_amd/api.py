@@ -328,6 +328,17 @@ class CircuitData:
         pb = self.proof_bytes
         return [buf.raw[i * pb:(i + 1) * pb] if status[i] == 0 else None for i in range(B)], list(status)
 
+    def prove_batch_device(self, targets, d_values, d_proofs, d_status, batch, stream=None):
+        """Device-resident path: `d_values` [batch][len(targets)] u64, `d_proofs` batch*proof_bytes bytes and `d_status`
+        int32[batch] are raw device pointers (e.g. torch tensors' data_ptr()); `stream` a raw hipStream_t or None."""
+        tarr = _arr(list(targets))
+        if lib().p2_prove_batch_device(self.gpu(), batch, tarr, len(targets), d_values, d_proofs, d_status, stream):
+            raise P2Error("p2_prove_batch_device failed: " + _err())
+
+    def synchronize(self):
+        if lib().p2_circuit_synchronize(self.gpu()):
+            raise P2Error(_err())
+
     def prove(self, pw):
         proofs, status = self.prove_batch([pw])
         if status[0]:

@@ -32,6 +32,7 @@ struct Tree {
 
 struct Workspace {
     hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;  // recorded after the last kernel of a call; the caller's stream waits on it
     u64* d_input_values = nullptr;
     u64* d_values = nullptr;
     u32* d_mult = nullptr;
@@ -453,6 +454,7 @@ static int alloc_workspace(p2_circuit* C, size_t chunk, u32 n_inputs, size_t nst
     C->ws.push_back(W);
     C->cur = W;
     if (hipStreamCreateWithFlags(&W->stream, hipStreamNonBlocking) != hipSuccess) return set_error("hipStreamCreate failed"), P2_ERR_HIP;
+    if (hipEventCreateWithFlags(&W->done, hipEventDisableTiming) != hipSuccess) return set_error("hipEventCreate failed"), P2_ERR_HIP;
     e |= dalloc(C, &C->cur->d_input_values, chunk * C->ws_inputs);
     e |= dalloc(C, &C->cur->d_values, chunk * c.num_slots);
     e |= dalloc(C, &C->cur->d_mult, chunk * std::max<size_t>(C->total_lut_entries, 1));
@@ -895,6 +897,7 @@ void p2_circuit_free(p2_circuit* C) {
     for (void* p : C->allocs) hipFree(p);
     for (Workspace* W : C->ws) {
         if (W->stream) hipStreamDestroy(W->stream);
+        if (W->done) hipEventDestroy(W->done);
         delete W;
     }
     if (C->stream) hipStreamDestroy(C->stream);
@@ -929,7 +932,7 @@ static int setup_polyrefs(p2_circuit* C) {
 int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets, size_t n_targets, const uint64_t* d_values, uint8_t* d_proofs, int* d_status,
                           void* stream) {
     std::lock_guard<std::mutex> lock(C->mu);
-    (void)stream;
+    hipStream_t caller = (hipStream_t)stream;
     HIPCHECK(hipSetDevice(C->device));
     std::vector<u32> slots(n_targets);
     for (size_t i = 0; i < n_targets; i++) {
@@ -964,8 +967,16 @@ int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets,
     size_t nstreams = C->chunk ? C->ws.size() : std::min(want_streams, (batch + chunk - 1) / chunk);
     if (alloc_workspace(C, chunk, (u32)n_targets, nstreams)) return P2_ERR_HIP;
     HIPCHECK(hipMemcpy(C->d_input_slots, slots.data(), n_targets * 4, hipMemcpyHostToDevice));
-    // the caller's inputs may have been produced on another stream (torch's current stream): make them visible
-    HIPCHECK(hipDeviceSynchronize());
+    // Ordering with the caller: with a stream, the proving streams wait for everything the caller has enqueued on it
+    // (its inputs) and the caller's stream then waits for the proofs; without one, the whole device is synchronised first.
+    hipEvent_t ev_in = nullptr;
+    if (caller) {
+        HIPCHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+        HIPCHECK(hipEventRecord(ev_in, caller));
+        for (Workspace* W : C->ws) HIPCHECK(hipStreamWaitEvent(W->stream, ev_in, 0));
+    } else {
+        HIPCHECK(hipDeviceSynchronize());
+    }
     size_t k = 0;
     for (size_t done = 0; done < batch; done += C->chunk, k++) {
         u32 B = (u32)std::min(C->chunk, batch - done);
@@ -973,6 +984,13 @@ int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets,
         int rc = prove_chunk(C, B, (u32)n_targets, d_values + done * n_targets, d_proofs + done * C->pbytes, d_status + done);
         C->cur = nullptr;
         if (rc) return rc;
+    }
+    if (caller) {
+        for (Workspace* W : C->ws) {
+            HIPCHECK(hipEventRecord(W->done, W->stream));
+            HIPCHECK(hipStreamWaitEvent(caller, W->done, 0));
+        }
+        HIPCHECK(hipEventDestroy(ev_in));
     }
     return P2_OK;
 }

@@ -272,3 +272,15 @@ def test_64kib_deep_circuit_2_19_rows(gpu):
     bad.map[k] ^= 0x80
     proofs2, status2 = data.prove_batch([pws[0], bad])
     assert status2 == [0, 1] and proofs2[0] == proofs[0]
+
+
+def test_c_example_over_the_abi(gpu, tmp_path):
+    """examples/aes_gcm_128.c: the reference's example program (aes-gcm/examples/aes_gcm_128.rs) from plain C."""
+    import subprocess
+    exe = str(tmp_path / "aes_gcm_128")
+    lib_dir = os.path.join(ROOT, "plonky2-aes_amd")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "aes_gcm_128.c"), "-o", exe,
+                           "-L" + lib_dir, "-lp2aes", "-Wl,-rpath," + lib_dir])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "proved and verified" in out.stdout and "status 1" in out.stdout
