@@ -54,7 +54,8 @@ typedef struct p2_builder p2_builder;
 /* Targets are opaque 64-bit handles (virtual target index, or a routed wire). */
 typedef uint64_t p2_target;
 
-p2_builder* p2_builder_new(void); /* CircuitConfig::standard_recursion_config() */
+p2_builder* p2_builder_new(void);    /* CircuitConfig::standard_recursion_config() */
+p2_builder* p2_builder_new_zk(void); /* CircuitConfig::standard_recursion_zk_config() (examples/aes_gcm_128.rs:36) */
 void p2_builder_free(p2_builder*);
 p2_target p2_builder_add_virtual_target(p2_builder*);
 p2_target p2_builder_constant(p2_builder*, uint64_t c);
@@ -146,6 +147,9 @@ typedef struct p2_circuit p2_circuit;
 p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device);
 void p2_circuit_free(p2_circuit*);
 int p2_circuit_verifier_data(const p2_circuit*, uint64_t* out, size_t cap, size_t* n_written);
+/* zk circuits only: blinding values are a keyed function of (seed, index of the proof since the seed was set), so a
+ * run is reproducible; the default seed is drawn from the OS at load time (upstream: OS randomness per proof). */
+int p2_circuit_set_zk_seed(p2_circuit*, uint64_t seed);
 size_t p2_circuit_proof_bytes(const p2_circuit*);
 /* One PartialWitness: (target, value) pairs, values canonical (< p). */
 typedef struct {

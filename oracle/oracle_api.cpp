@@ -32,6 +32,11 @@ void orc_circuit_free(void* hp) {
     delete h;
 }
 uint32_t orc_degree_bits(void* hp) { return ((Handle*)hp)->c->degree_bits; }
+// zk circuits: blinding seed and index of the next proof (same keyed RNG as the product)
+void orc_set_zk(void* hp, uint64_t seed, uint64_t proof_index) {
+    ((Handle*)hp)->c->zk_seed = seed;
+    ((Handle*)hp)->c->zk_proof = proof_index;
+}
 // verifier-only data: constants_sigmas_cap (2^cap_height digests) followed by circuit_digest; returns #u64
 size_t orc_verifier_data(void* hp, uint64_t* out, size_t cap) {
     Handle* h = (Handle*)hp;

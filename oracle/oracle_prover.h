@@ -21,8 +21,22 @@ namespace orc {
 
 struct OConfig {
     u32 num_wires, num_routed_wires, num_constants, num_challenges, quotient_degree_factor, rate_bits, cap_height, pow_bits,
-        num_query_rounds, arity_bits, final_poly_bits;
+        num_query_rounds, arity_bits, final_poly_bits, zero_knowledge;
 };
+// keyed blinding randomness, shared definition with the product (circuit.h zk_rand): SplitMix64 finaliser mod p
+static inline u64 zk_rand(u64 seed, u64 proof, u64 domain, u64 index) {
+    u64 x = seed ^ (proof * 0x9E3779B97F4A7C15ull) ^ (domain << 56);
+    for (int round = 0; round < 2; round++) {
+        x += 0x9E3779B97F4A7C15ull + (round ? index : 0);
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        x ^= index * 0xD6E8FEB86659FD93ull;
+    }
+    x = (x ^ (x >> 32)) * 0xD6E8FEB86659FD93ull;
+    x ^= x >> 29;
+    return x % MODULUS;
+}
 struct OOp {
     u32 kind, out, a, b, c, aux;
     u64 k0, k1;
@@ -55,6 +69,7 @@ struct Reader {
 // PolynomialBatch
 struct Batch {
     size_t cols = 0;
+    size_t width = 0;                       // leaf width = cols (+ 4 salt elements for a blinded oracle in zk mode)
     std::vector<std::vector<u64>> coeffs;  // [cols][n]
     std::vector<u64> lde;                  // [8n][cols], leaf index = bit-reversed domain index
     MerkleTree tree;
@@ -74,7 +89,9 @@ struct OCircuit {
     std::vector<OOp> ops;
     std::vector<u32> level_offsets;
     std::vector<int32_t> vt_slot, wire_slot;
-    std::vector<u32> poseidon_rows;
+    std::vector<u32> poseidon_rows, blind_rows;
+    std::vector<std::pair<u32, u32>> blind_zrows;
+    u64 zk_seed = 0, zk_proof = 0;  // set per proof by the caller (orc_set_zk)
     // derived
     size_t n;
     int lde_bits;
@@ -101,22 +118,27 @@ struct OCircuit {
 
 typedef std::map<std::string, std::vector<u64>> Trace;
 
-static inline void commit_from_coeffs(const OCircuit& C, Batch& b) {
+// oracle_index 0 = constants|sigmas (never blinded); 1 wires, 2 zs/partial products/lookups, 3 quotient
+static inline void commit_from_coeffs(const OCircuit& C, Batch& b, int oracle_index) {
     size_t n = C.n, N = n << C.cfg.rate_bits, cols = b.cols;
-    b.lde.assign(N * cols, 0);
+    size_t salt = (C.cfg.zero_knowledge && oracle_index > 0) ? 4 : 0;
+    b.width = cols + salt;
+    b.lde.assign(N * b.width, 0);
 #pragma omp parallel for schedule(dynamic, 1)
     for (size_t c = 0; c < cols; c++) {
         std::vector<u64> v = coset_fft(b.coeffs[c], C.lde_bits, GENERATOR);
-        for (size_t i = 0; i < N; i++) b.lde[rev_bits(i, C.lde_bits) * cols + c] = v[i];
+        for (size_t i = 0; i < N; i++) b.lde[rev_bits(i, C.lde_bits) * b.width + c] = v[i];
     }
-    b.tree = build_merkle(b.lde.data(), N, cols, C.cfg.cap_height);
+    for (size_t s = 0; s < salt; s++)
+        for (size_t pos = 0; pos < N; pos++) b.lde[pos * b.width + cols + s] = zk_rand(C.zk_seed, C.zk_proof, 3 + oracle_index, s * N + pos);
+    b.tree = build_merkle(b.lde.data(), N, b.width, C.cfg.cap_height);
 }
-static inline void commit_from_values(const OCircuit& C, Batch& b, const std::vector<std::vector<u64>>& values) {
+static inline void commit_from_values(const OCircuit& C, Batch& b, const std::vector<std::vector<u64>>& values, int oracle_index) {
     b.cols = values.size();
     b.coeffs = values;
 #pragma omp parallel for schedule(dynamic, 1)
     for (size_t c = 0; c < b.cols; c++) fft_inplace(b.coeffs[c].data(), C.degree_bits, true);
-    commit_from_coeffs(C, b);
+    commit_from_coeffs(C, b, oracle_index);
 }
 
 static inline OCircuit* load_circuit(const void* blob, size_t len) {
@@ -124,7 +146,7 @@ static inline OCircuit* load_circuit(const void* blob, size_t len) {
     char magic[8];
     r.get(magic, 8);
     if (memcmp(magic, "P2AESCIR", 8) != 0) throw std::runtime_error("oracle: bad magic");
-    if (r.g32() != 2) throw std::runtime_error("oracle: bad version");
+    if (r.g32() != 3) throw std::runtime_error("oracle: bad version");
     OCircuit* C = new OCircuit();
     r.get(&C->cfg, sizeof(OConfig));
     C->degree_bits = r.g32();
@@ -146,6 +168,8 @@ static inline OCircuit* load_circuit(const void* blob, size_t len) {
     C->vt_slot = r.arr<int32_t>();
     C->wire_slot = r.arr<int32_t>();
     C->poseidon_rows = r.arr<u32>();
+    C->blind_rows = r.arr<u32>();
+    C->blind_zrows = r.arr<std::pair<u32, u32>>();
     C->n = (size_t)1 << C->degree_bits;
     C->lde_bits = C->degree_bits + C->cfg.rate_bits;
     for (auto& lut : C->luts) {
@@ -159,7 +183,7 @@ static inline OCircuit* load_circuit(const void* blob, size_t len) {
     std::vector<std::vector<u64>> vals(ncc + R, std::vector<u64>(n));
     for (size_t c = 0; c < ncc; c++) memcpy(vals[c].data(), &C->constants[c * n], n * 8);
     for (size_t c = 0; c < R; c++) memcpy(vals[ncc + c].data(), &C->sigmas[c * n], n * 8);
-    commit_from_values(*C, C->pre, vals);
+    commit_from_values(*C, C->pre, vals, 0);
     std::vector<u64> parts;
     for (auto& d : C->pre.tree.cap())
         for (int i = 0; i < 4; i++) parts.push_back(d.e[i]);
@@ -302,6 +326,15 @@ static inline int generate_witness(const OCircuit& C, const u64* in_targets, con
                 if (val[s] == UNSET) return 2;
                 wires[c][row] = val[s];
             }
+        }
+    // zk blinding rows (RandomValueGenerators of blind_and_pad)
+    for (size_t k = 0; k < C.blind_rows.size(); k++)
+        for (size_t c = 0; c < C.cfg.num_wires; c++) wires[c][C.blind_rows[k]] = zk_rand(C.zk_seed, C.zk_proof, 1, k * C.cfg.num_wires + c);
+    for (size_t k = 0; k < C.blind_zrows.size(); k++)
+        for (size_t c = 0; c < R; c++) {
+            u64 v = zk_rand(C.zk_seed, C.zk_proof, 2, k * R + c);
+            wires[c][C.blind_zrows[k].first] = v;
+            wires[c][C.blind_zrows[k].second] = v;
         }
     for (size_t k = 0; k < C.poseidon_rows.size(); k++) {
         if (pos_rows[k].empty()) return 2;
@@ -507,7 +540,7 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
     }
     // 2. wires commitment
     Batch wb;
-    commit_from_values(C, wb, wires);
+    commit_from_values(C, wb, wires, 1);
     tr("wires_cap", flat_cap(wb.tree));
     // 3. challenger
     Challenger chal;
@@ -600,7 +633,7 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
         tr("zs", f);
     }
     Batch zb;
-    commit_from_values(C, zb, zcols);
+    commit_from_values(C, zb, zcols, 2);
     tr("zs_cap", flat_cap(zb.tree));
     chal.observe_cap(zb.tree.cap());
     for (size_t i = 0; i < NC; i++) ch.alphas.push_back(chal.challenge());
@@ -622,17 +655,17 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
         std::vector<u64> zh_inv((size_t)1 << C.cfg.rate_bits);
         u64 gn = fpow(GENERATOR, n), w8 = root_of_unity(C.cfg.rate_bits);
         for (size_t j = 0; j < zh_inv.size(); j++) zh_inv[j] = finv(fsub(fmul(gn, fpow(w8, j)), 1));
-        const size_t zc = zb.cols, step = (size_t)1 << C.cfg.rate_bits;
+        const size_t step = (size_t)1 << C.cfg.rate_bits;
         u64 n_inv = finv(n);
 #pragma omp parallel for schedule(static)
         for (size_t i = 0; i < N; i++) {
             size_t li = rev_bits(i, C.lde_bits), ln = rev_bits((i + step) % N, C.lde_bits);
             PointVars v;
-            v.consts = &C.pre.lde[li * C.pre.cols];
+            v.consts = &C.pre.lde[li * C.pre.width];
             v.sigmas = v.consts + ncc;
-            v.wires = &wb.lde[li * wb.cols];
-            v.zs = &zb.lde[li * zc];
-            v.zs_next = &zb.lde[ln * zc];
+            v.wires = &wb.lde[li * wb.width];
+            v.zs = &zb.lde[li * zb.width];
+            v.zs_next = &zb.lde[ln * zb.width];
             u64 x = xs[i];
             u64 zh = fsub(fmul(gn, fpow(w8, i % step)), 1);
             // L_0(x) = (x^n - 1) / (n (x - 1))
@@ -653,7 +686,7 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
             for (auto& c : qb.coeffs) f.insert(f.end(), c.begin(), c.end());
             tr("quotient_coeffs", f);
         }
-        commit_from_coeffs(C, qb);
+        commit_from_coeffs(C, qb, 3);
     }
     tr("quotient_cap", flat_cap(qb.tree));
     chal.observe_cap(qb.tree.cap());
@@ -837,7 +870,7 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
         qidx.push_back(x_index);
         for (int o = 0; o < 4; o++) {
             const Batch* b = oracles[o];
-            for (size_t c = 0; c < b->cols; c++) w.w64(b->lde[x_index * b->cols + c]);
+            for (size_t c = 0; c < b->width; c++) w.w64(b->lde[x_index * b->width + c]);
             w.merkle_proof(b->tree.prove(x_index));
         }
         for (size_t r = 0; r < arities.size(); r++) {

@@ -65,7 +65,8 @@ def lib():
     vp = C.c_void_p
     sig = {
         "p2_last_error": (C.c_char_p, []),
-        "p2_builder_new": (vp, []), "p2_builder_free": (None, [vp]),
+        "p2_builder_new": (vp, []), "p2_builder_new_zk": (vp, []), "p2_builder_free": (None, [vp]),
+        "p2_circuit_set_zk_seed": (C.c_int, [vp, u64]),
         "p2_builder_add_virtual_target": (u64, [vp]), "p2_builder_constant": (u64, [vp, u64]),
         "p2_builder_zero": (u64, [vp]), "p2_builder_one": (u64, [vp]),
         "p2_builder_arithmetic": (u64, [vp, u64, u64, u64, u64, u64]),
@@ -142,8 +143,9 @@ def _arr(vals):
 
 
 class CircuitBuilder:
-    def __init__(self):
-        self._h = lib().p2_builder_new()
+    def __init__(self, zero_knowledge=False):
+        """CircuitBuilder::<F, D>::new(standard_recursion_config()) or, with zero_knowledge, standard_recursion_zk_config()."""
+        self._h = lib().p2_builder_new_zk() if zero_knowledge else lib().p2_builder_new()
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -334,6 +336,10 @@ class CircuitData:
         tarr = _arr(list(targets))
         if lib().p2_prove_batch_device(self.gpu(), batch, tarr, len(targets), d_values, d_proofs, d_status, stream):
             raise P2Error("p2_prove_batch_device failed: " + _err())
+
+    def set_zk_seed(self, seed):
+        if lib().p2_circuit_set_zk_seed(self.gpu(), seed):
+            raise P2Error(_err())
 
     def synchronize(self):
         if lib().p2_circuit_synchronize(self.gpu()):

@@ -316,7 +316,38 @@ inline Circuit CircuitBuilder::build() {
             gens_.push_back(Gen{OP_CONST, w, 0, 0, 0, 0, kv.first, 0});
         }
     }
-    // blind_and_pad (non-zk): pad with NoopGates to a power of two.
+    // blind_and_pad.  zk: blinding_counts() rows of random wires for the regular polynomials, and pairs of rows with
+    // equal (copy-constrained) random routed wires for the Z polynomials; then pad with NoopGates to a power of two.
+    if (cfg_.zero_knowledge) {
+        const size_t D = 2, num_gates_now = gate_instances_.size();
+        size_t degree_estimate = 1;
+        while (degree_estimate < num_gates_now) degree_estimate <<= 1;
+        size_t regular = 0, zopen = 0;
+        for (;;) {
+            u32 db_est = 0;
+            while (((size_t)1 << db_est) < degree_estimate) db_est++;
+            Circuit tmp;
+            tmp.cfg = cfg_;
+            tmp.degree_bits = db_est;
+            size_t folding = 0, prod = 1;
+            for (u32 a : tmp.reduction_arity_bits()) {
+                folding += ((size_t)1 << a) - 1;
+                prod <<= a;
+            }
+            size_t final_coeffs = degree_estimate / prod;
+            size_t fri_openings = cfg_.num_query_rounds * (1 + D * folding + D * final_coeffs);
+            regular = D + fri_openings;
+            zopen = 2 * D + fri_openings;
+            if (num_gates_now + regular + 2 * zopen <= degree_estimate) break;
+            degree_estimate <<= 1;
+        }
+        for (size_t i = 0; i < regular; i++) c.blind_rows.push_back(add_gate(G_NOOP));
+        for (size_t i = 0; i < zopen; i++) {
+            u32 g1 = add_gate(G_NOOP), g2 = add_gate(G_NOOP);
+            for (u32 w = 0; w < R; w++) connect(wire_target(g1, w), wire_target(g2, w));
+            c.blind_zrows.push_back({g1, g2});
+        }
+    }
     while (gate_instances_.size() < 4 || (gate_instances_.size() & (gate_instances_.size() - 1)) != 0) add_gate(G_NOOP);
     const size_t n = gate_instances_.size();
     u32 db = 0;

@@ -19,7 +19,7 @@ inline size_t proof_words(const Circuit& c, size_t* n_merkle_proofs) {
                     c.num_quotient_cols() + 2 * NC * c.num_lookup_polys();
     w += 2 * n_open;
     w += ar.size() * cap_n * 4;
-    size_t per_q = c.num_preprocessed() + c.cfg.num_wires + c.num_zs_cols() + c.num_quotient_cols() + 4 * 4 * (lde_bits - c.cfg.cap_height);
+    size_t per_q = c.num_preprocessed() + c.cfg.num_wires + c.num_zs_cols() + c.num_quotient_cols() + 3 * c.salt() + 4 * 4 * (lde_bits - c.cfg.cap_height);
     size_t mp = 4;
     size_t bits = lde_bits;
     for (u32 a : ar) {

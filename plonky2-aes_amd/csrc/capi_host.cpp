@@ -23,6 +23,11 @@ extern "C" {
 const char* p2_last_error(void) { return p2::g_last_error.c_str(); }
 
 p2_builder* p2_builder_new(void) { return new p2_builder(); }
+p2_builder* p2_builder_new_zk(void) {
+    Config cfg;
+    cfg.zero_knowledge = 1;
+    return new p2_builder{CircuitBuilder(cfg)};
+}
 void p2_builder_free(p2_builder* b) { delete b; }
 p2_target p2_builder_add_virtual_target(p2_builder* b) { return b->b.add_virtual_target(); }
 p2_target p2_builder_constant(p2_builder* b, uint64_t c) { return b->b.constant(c); }

@@ -34,7 +34,30 @@ struct Config {
     u32 num_query_rounds = 28;
     u32 arity_bits = 4;       // FriReductionStrategy::ConstantArityBits(4, 5)
     u32 final_poly_bits = 5;
+    u32 zero_knowledge = 0;   // standard_recursion_zk_config(): blinding rows + salted Merkle leaves
 };
+static const u32 SALT_SIZE = 4;  // plonky2 fri::oracle SALT_SIZE: random elements appended to every leaf of a blinded oracle
+
+// Blinding randomness.  Upstream draws from the OS RNG (proofs are not reproducible); here every random element is a
+// keyed function of (seed, proof index, domain, index) so that the GPU prover and the CPU oracle produce identical
+// proofs.  SplitMix64 finaliser, reduced mod p (bias 2^-32, irrelevant for blinding).
+enum ZkDomain : u64 { ZK_ROW = 1, ZK_ZROW = 2, ZK_SALT = 3 /* + oracle index */ };
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline u64 zk_rand(u64 seed, u64 proof, u64 domain, u64 index) {
+    u64 x = seed ^ (proof * 0x9E3779B97F4A7C15ull) ^ (domain << 56);
+    for (int round = 0; round < 2; round++) {
+        x += 0x9E3779B97F4A7C15ull + (round ? index : 0);
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        x ^= index * 0xD6E8FEB86659FD93ull;
+    }
+    x = (x ^ (x >> 32)) * 0xD6E8FEB86659FD93ull;
+    x ^= x >> 29;
+    return x % 0xFFFFFFFF00000001ull;
+}
 
 // Gate kinds in plonky2's sort order (degree, id) for the gates the gadget crates instantiate.
 enum GateKind : u32 {
@@ -99,6 +122,10 @@ struct Circuit {
     std::vector<int32_t> vt_slot;                // virtual target index -> slot (or -1)
     std::vector<int32_t> wire_slot;              // [num_routed][n] -> slot (or -1 = unconnected)
     std::vector<u32> poseidon_rows;              // rows holding a PoseidonGate; index = advice block of the row
+    // zk blinding (blind_and_pad): NoopGate rows whose 135 wires are random, and pairs of NoopGate rows whose 80
+    // routed wires carry the same random value (copy-constrained), for the Z polynomials
+    std::vector<u32> blind_rows;
+    std::vector<std::pair<u32, u32>> blind_zrows;
 
     u32 n() const { return 1u << degree_bits; }
     u32 num_selectors() const { return (u32)groups.size(); }
@@ -111,6 +138,7 @@ struct Circuit {
     u32 num_zs_pp() const { return cfg.num_challenges * (1 + num_partial_products()); }
     u32 num_zs_cols() const { return num_zs_pp() + cfg.num_challenges * num_lookup_polys(); }
     u32 num_quotient_cols() const { return cfg.num_challenges * cfg.quotient_degree_factor; }
+    u32 salt() const { return cfg.zero_knowledge ? SALT_SIZE : 0; }  // extra leaf elements of the wires / zs / quotient oracles
     // FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits).reduction_arity_bits(...)
     std::vector<u32> reduction_arity_bits() const {
         std::vector<u32> r;
@@ -160,7 +188,7 @@ struct BlobReader {
 };
 
 static const char BLOB_MAGIC[8] = {'P', '2', 'A', 'E', 'S', 'C', 'I', 'R'};
-static const u32 BLOB_VERSION = 2;
+static const u32 BLOB_VERSION = 3;
 
 static inline std::vector<uint8_t> serialize(const Circuit& c) {
     BlobWriter w;
@@ -186,6 +214,8 @@ static inline std::vector<uint8_t> serialize(const Circuit& c) {
     w.vec(c.vt_slot);
     w.vec(c.wire_slot);
     w.vec(c.poseidon_rows);
+    w.vec(c.blind_rows);
+    w.vec(c.blind_zrows);
     return w.buf;
 }
 
@@ -217,6 +247,8 @@ static inline Circuit deserialize(const void* data, size_t len) {
     r.vec(c.vt_slot);
     r.vec(c.wire_slot);
     r.vec(c.poseidon_rows);
+    r.vec(c.blind_rows);
+    r.vec(c.blind_zrows);
     // shape checks: everything a kernel indexes with is validated here, once.
     size_t n = c.n();
     if (c.degree_bits > 26) throw std::runtime_error("degree_bits too large");
@@ -238,6 +270,10 @@ static inline Circuit deserialize(const void* data, size_t len) {
     }
     for (auto s : c.wire_slot)
         if (s >= (int32_t)c.num_slots) throw std::runtime_error("wire slot range");
+    for (u32 row : c.blind_rows)
+        if (row >= n) throw std::runtime_error("blinding row");
+    for (auto pr : c.blind_zrows)
+        if (pr.first >= n || pr.second >= n) throw std::runtime_error("blinding row pair");
     for (u32 row : c.poseidon_rows) {
         if (row >= n) throw std::runtime_error("poseidon row");
         for (u32 col = 0; col < c.cfg.num_routed_wires; col++)

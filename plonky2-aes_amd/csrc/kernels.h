@@ -460,6 +460,32 @@ __global__ void k_fill_advice(const int32_t* __restrict__ pos_index /*[n]: advic
     wires[(size_t)blockIdx.y * wires_batch_stride + (size_t)(80 + c) * n + row] = v;
 }
 
+// zk blinding rows: every wire of a `rows` entry is random; the 80 routed wires of both rows of a `zrows` pair carry the
+// same random value (they are copy-constrained)
+__global__ void k_fill_blind(const u32* __restrict__ rows, u32 n_rows, const u32* __restrict__ zrows, u32 n_z, u64* __restrict__ wires,
+                             size_t wires_batch_stride, u32 n, u64 seed, u64 proof_base) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u64* w = wires + (size_t)blockIdx.y * wires_batch_stride;
+    const u64 proof = proof_base + blockIdx.y;
+    const size_t regular = (size_t)n_rows * 135;
+    if (idx < regular) {
+        u32 k = (u32)(idx / 135), c = (u32)(idx % 135);
+        w[(size_t)c * n + rows[k]] = p2::zk_rand(seed, proof, p2::ZK_ROW, idx);
+    } else if (idx < regular + (size_t)n_z * 80) {
+        size_t j = idx - regular;
+        u32 k = (u32)(j / 80), c = (u32)(j % 80);
+        u64 v = p2::zk_rand(seed, proof, p2::ZK_ZROW, j);
+        w[(size_t)c * n + zrows[2 * k]] = v;
+        w[(size_t)c * n + zrows[2 * k + 1]] = v;
+    }
+}
+// SALT_SIZE random columns appended to a blinded oracle's LDE matrix (they are leaf data only, not polynomials)
+__global__ void k_fill_salt(u64* __restrict__ salt_cols, size_t batch_stride, size_t N, u64 seed, u64 proof_base, u64 domain) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p2::SALT_SIZE * N) return;
+    salt_cols[(size_t)blockIdx.y * batch_stride + idx] = p2::zk_rand(seed, proof_base + blockIdx.y, domain, idx);
+}
+
 struct LutRowsArgs {
     const u32* lut_pairs;
     const u32* lut_offsets;

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <random>
 #include <string>
 
 #include "capi_common.h"
@@ -69,6 +70,8 @@ struct p2_circuit {
     u32 *d_lut_pairs = nullptr, *d_lut_offsets = nullptr, *d_num_lookups = nullptr;
     LookupRows* d_lookup_rows = nullptr;
     int32_t* d_pos_index = nullptr;  // [n] advice block of a PoseidonGate row, else -1
+    u32 *d_blind_rows = nullptr, *d_blind_zrows = nullptr;
+    u64 zk_seed = 0, zk_counter = 0;  // keyed blinding randomness (zk circuits)
     size_t total_lut_entries = 0;
     u64 *d_sigmas = nullptr, *d_k_is = nullptr, *d_subgroup = nullptr;
     u64 *d_tw_fwd = nullptr, *d_tw_inv = nullptr;  // w^k / w^-k for k < n_max/2, n_max = n
@@ -300,6 +303,8 @@ static int circuit_setup(p2_circuit* C) {
         for (size_t k = 0; k < c.poseidon_rows.size(); k++) pi[c.poseidon_rows[k]] = (int32_t)k;
         if (upload(C, &C->d_pos_index, pi.data(), n)) return P2_ERR_HIP;
     }
+    if (upload(C, &C->d_blind_rows, c.blind_rows.data(), c.blind_rows.size())) return P2_ERR_HIP;
+    if (upload(C, &C->d_blind_zrows, (const u32*)c.blind_zrows.data(), 2 * c.blind_zrows.size())) return P2_ERR_HIP;
     if (upload(C, &C->d_sigmas, c.sigmas.data(), c.sigmas.size())) return P2_ERR_HIP;
     if (upload(C, &C->d_k_is, c.k_is.data(), c.k_is.size())) return P2_ERR_HIP;
     // twiddles, subgroup, coset tables (host-computed once; O(n) field ops)
@@ -462,16 +467,16 @@ static int alloc_workspace(p2_circuit* C, size_t chunk, u32 n_inputs, size_t nst
     e |= dalloc(C, &C->cur->d_advice, chunk * std::max<size_t>(c.poseidon_rows.size(), 1) * 55);
     e |= dalloc(C, &C->cur->d_wires, chunk * act * n);
     e |= dalloc(C, &C->cur->d_wcoef, chunk * act * n);
-    e |= dalloc(C, &C->cur->d_wlde, chunk * act * N);
+    e |= dalloc(C, &C->cur->d_wlde, chunk * (act + c.salt()) * N);
     e |= dalloc(C, &C->cur->d_zs, chunk * zc * n);
     e |= dalloc(C, &C->cur->d_zcoef, chunk * zc * n);
-    e |= dalloc(C, &C->cur->d_zlde, chunk * zc * N);
+    e |= dalloc(C, &C->cur->d_zlde, chunk * (zc + c.salt()) * N);
     e |= dalloc(C, &C->cur->d_permq, chunk * NC * (c.num_partial_products() + 1) * n);
     e |= dalloc(C, &C->cur->d_lktmp, chunk * NC * (c.num_sldc_polys() + 1) * n);
     e |= dalloc(C, &C->cur->d_qvals, chunk * NC * N);
     e |= dalloc(C, &C->cur->d_qres, chunk * NC * N);
     e |= dalloc(C, &C->cur->d_qcoef, chunk * qc * n);
-    e |= dalloc(C, &C->cur->d_qlde, chunk * qc * N);
+    e |= dalloc(C, &C->cur->d_qlde, chunk * (qc + c.salt()) * N);
     for (Tree* t : {&C->cur->wtree, &C->cur->ztree, &C->cur->qtree}) {
         t->bits = C->lde_bits;
         e |= dalloc(C, &t->dig, chunk * t->stride());
@@ -504,13 +509,14 @@ static int alloc_workspace(p2_circuit* C, size_t chunk, u32 n_inputs, size_t nst
 
 // ---------------------------------------------------------------------------------- the pipeline
 // d_targets_slots already uploaded to C->d_input_slots; d_values: [batch][n_inputs] device; proofs/status: device.
-static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, uint8_t* d_proofs, int* d_status_out) {
+static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, uint8_t* d_proofs, int* d_status_out, u64 proof_base) {
     const Circuit& c = C->c;
     const size_t n = C->n, N = C->N;
     const u32 R = c.cfg.num_routed_wires, NC = c.cfg.num_challenges, npp = c.num_partial_products(), nlp = c.num_lookup_polys();
     const u32 zc = c.num_zs_cols(), qc = c.num_quotient_cols(), act = C->active_wires, ncc = c.num_constants_cols(), np = c.num_preprocessed();
     const u32 cap_h = c.cfg.cap_height, cap_words = 4u << cap_h, nsldc = c.num_sldc_polys();
-    const size_t ws = (size_t)act * n, wls = (size_t)act * N, zs_s = (size_t)zc * n, zl_s = (size_t)zc * N;
+    const u32 salt = c.salt();
+    const size_t ws = (size_t)act * n, wls = (size_t)(act + salt) * N, zs_s = (size_t)zc * n, zl_s = (size_t)(zc + salt) * N, ql_s = (size_t)(qc + salt) * N;
     hipStream_t st = C->cur_stream();
     // 1. witness
     HIPCHECK(hipMemsetAsync(C->cur->d_mult, 0, (size_t)B * std::max<size_t>(C->total_lut_entries, 1) * 4, st));
@@ -541,6 +547,11 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
     if (act > R)
         LAUNCH(C, "fill_advice", k_fill_advice, g1((size_t)55 * n, 256, B), dim3(256), 0, C->d_pos_index, C->cur->d_advice, C->cur->d_wires, (u32)n,
                (u32)c.poseidon_rows.size(), ws);
+    if (c.cfg.zero_knowledge) {
+        size_t cnt = c.blind_rows.size() * 135 + c.blind_zrows.size() * 80;
+        LAUNCH(C, "fill_blind", k_fill_blind, g1(std::max<size_t>(cnt, 1), 256, B), dim3(256), 0, C->d_blind_rows, (u32)c.blind_rows.size(), C->d_blind_zrows,
+               (u32)c.blind_zrows.size(), C->cur->d_wires, ws, (u32)n, C->zk_seed, proof_base);
+    }
     if (!c.luts.empty()) {
         LutRowsArgs a{};
         a.lut_pairs = C->d_lut_pairs;
@@ -558,7 +569,8 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
     // 2. wires commitment
     if (intt_cols(C, C->cur->d_wires, C->cur->d_wcoef, act, ws, B, C->cur->d_wlde, wls)) return P2_ERR_HIP;
     if (lde_cols(C, C->cur->d_wcoef, ws, C->cur->d_wlde, wls, act, 0, B)) return P2_ERR_HIP;
-    if (merkle_build(C, C->cur->d_wlde, c.cfg.num_wires, act, N, wls, C->cur->wtree, B)) return P2_ERR_HIP;
+    if (salt) LAUNCH(C, "fill_salt", k_fill_salt, g1((size_t)salt * N, 256, B), dim3(256), 0, C->cur->d_wlde + (size_t)act * N, wls, N, C->zk_seed, proof_base, (u64)ZK_SALT + 1);
+    if (merkle_build(C, C->cur->d_wlde, c.cfg.num_wires + salt, act + salt, N, wls, C->cur->wtree, B)) return P2_ERR_HIP;
     // 3. betas, gammas, deltas
     if (challenger(C, 0, C->cur->wtree.dig + cap_off(C->cur->wtree, cap_h), C->cur->wtree.stride(), cap_words, nlp ? 1 : 0, 0, B)) return P2_ERR_HIP;
     // 4. partial products and Z
@@ -590,7 +602,8 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
     // 6. zs commitment, alphas
     if (intt_cols(C, C->cur->d_zs, C->cur->d_zcoef, zc, zs_s, B, C->cur->d_zlde, zl_s)) return P2_ERR_HIP;
     if (lde_cols(C, C->cur->d_zcoef, zs_s, C->cur->d_zlde, zl_s, zc, 0, B)) return P2_ERR_HIP;
-    if (merkle_build(C, C->cur->d_zlde, zc, zc, N, zl_s, C->cur->ztree, B)) return P2_ERR_HIP;
+    if (salt) LAUNCH(C, "fill_salt", k_fill_salt, g1((size_t)salt * N, 256, B), dim3(256), 0, C->cur->d_zlde + (size_t)zc * N, zl_s, N, C->zk_seed, proof_base, (u64)ZK_SALT + 2);
+    if (merkle_build(C, C->cur->d_zlde, zc + salt, zc + salt, N, zl_s, C->cur->ztree, B)) return P2_ERR_HIP;
     if (challenger(C, 1, C->cur->ztree.dig + cap_off(C->cur->ztree, cap_h), C->cur->ztree.stride(), cap_words, 0, 0, B)) return P2_ERR_HIP;
     // 7. quotient
     {
@@ -673,8 +686,9 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         LAUNCH(C, "quotient_chunks", k_quotient_chunks_rev, g1(n, 256, B, NC), dim3(256), 0, C->cur->d_qres, C->cur->d_qcoef, (u32)n, (size_t)NC * N, (size_t)qc * n,
                C->d_w8inv, C->d_qscale);
     }
-    if (lde_cols(C, C->cur->d_qcoef, (size_t)qc * n, C->cur->d_qlde, (size_t)qc * N, qc, 0, B)) return P2_ERR_HIP;
-    if (merkle_build(C, C->cur->d_qlde, qc, qc, N, (size_t)qc * N, C->cur->qtree, B)) return P2_ERR_HIP;
+    if (lde_cols(C, C->cur->d_qcoef, (size_t)qc * n, C->cur->d_qlde, ql_s, qc, 0, B)) return P2_ERR_HIP;
+    if (salt) LAUNCH(C, "fill_salt", k_fill_salt, g1((size_t)salt * N, 256, B), dim3(256), 0, C->cur->d_qlde + (size_t)qc * N, ql_s, N, C->zk_seed, proof_base, (u64)ZK_SALT + 3);
+    if (merkle_build(C, C->cur->d_qlde, qc + salt, qc + salt, N, ql_s, C->cur->qtree, B)) return P2_ERR_HIP;
     if (challenger(C, 2, C->cur->qtree.dig + cap_off(C->cur->qtree, cap_h), C->cur->qtree.stride(), cap_words, c.degree_bits, 0, B)) return P2_ERR_HIP;
     // 8. openings
     LAUNCH(C, "zeta_pows", k_zeta_pows, g1(n, 256, B, 4), dim3(256), 0, C->cur->d_chal, C->cur->d_pows, (size_t)8 * n, (u32)n, gl::root_of_unity((int)C->logn));
@@ -743,10 +757,10 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         }
         QueryArgs q{};
         const u64* ldes[4] = {C->d_pre_lde, C->cur->d_wlde, C->cur->d_zlde, C->cur->d_qlde};
-        const size_t lstr[4] = {0, wls, zl_s, (size_t)qc * N};
+        const size_t lstr[4] = {0, wls, zl_s, ql_s};
         const Tree* trees[4] = {&C->pre_tree, &C->cur->wtree, &C->cur->ztree, &C->cur->qtree};
-        const u32 colsv[4] = {np, c.cfg.num_wires, zc, qc};
-        const u32 actv[4] = {np, act, zc, qc};
+        const u32 colsv[4] = {np, c.cfg.num_wires + salt, zc + salt, qc + salt};  // blinded leaves end with the salt
+        const u32 actv[4] = {np, act + salt, zc + salt, qc + salt};
         size_t qbytes = 0;
         for (int o = 0; o < 4; o++) {
             q.oracles[o].lde = ldes[o];
@@ -842,7 +856,11 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
         C->N = C->n << c.cfg.rate_bits;
         C->arities = c.reduction_arity_bits();
         // routed-only gates leave wires 80..134 identically zero (never materialised); PoseidonGate rows use all 135
-        C->active_wires = c.poseidon_rows.empty() ? c.cfg.num_routed_wires : c.cfg.num_wires;
+        C->active_wires = (c.poseidon_rows.empty() && !c.cfg.zero_knowledge) ? c.cfg.num_routed_wires : c.cfg.num_wires;
+        {
+            std::random_device rd;
+            C->zk_seed = ((u64)rd() << 32) ^ rd();
+        }
         C->pbytes = proof_bytes(c);
         if (hipSetDevice(device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
         if (hipStreamCreate(&C->stream) != hipSuccess) throw std::runtime_error("hipStreamCreate failed");
@@ -911,6 +929,12 @@ int p2_circuit_verifier_data(const p2_circuit* C, uint64_t* out, size_t cap, siz
     return P2_OK;
 }
 size_t p2_circuit_proof_bytes(const p2_circuit* C) { return C->pbytes; }
+int p2_circuit_set_zk_seed(p2_circuit* C, uint64_t seed) {
+    std::lock_guard<std::mutex> lock(C->mu);
+    C->zk_seed = seed;
+    C->zk_counter = 0;
+    return P2_OK;
+}
 
 static int setup_polyrefs(p2_circuit* C) {
     const Circuit& c = C->c;
@@ -981,10 +1005,11 @@ int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets,
     for (size_t done = 0; done < batch; done += C->chunk, k++) {
         u32 B = (u32)std::min(C->chunk, batch - done);
         C->cur = C->ws[k % C->ws.size()];
-        int rc = prove_chunk(C, B, (u32)n_targets, d_values + done * n_targets, d_proofs + done * C->pbytes, d_status + done);
+        int rc = prove_chunk(C, B, (u32)n_targets, d_values + done * n_targets, d_proofs + done * C->pbytes, d_status + done, C->zk_counter + done);
         C->cur = nullptr;
         if (rc) return rc;
     }
+    C->zk_counter += batch;
     if (caller) {
         for (Workspace* W : C->ws) {
             HIPCHECK(hipEventRecord(W->done, W->stream));
@@ -1104,7 +1129,7 @@ int p2_circuit_debug_read(p2_circuit* C, const char* name_c, size_t index, uint6
     else if (name == "values") { src = C->cur->d_values + index * c.num_slots; count = c.num_slots; }
     else if (name == "wires") { src = C->cur->d_wires + index * act * n; count = (size_t)act * n; }
     else if (name == "wires_coeffs") { src = C->cur->d_wcoef + index * act * n; count = (size_t)act * n; }
-    else if (name == "wires_lde") { src = C->cur->d_wlde + index * act * N; count = (size_t)act * N; }
+    else if (name == "wires_lde") { src = C->cur->d_wlde + index * (act + c.salt()) * N; count = (size_t)(act + c.salt()) * N; }
     else if (name == "wires_cap") { src = C->cur->wtree.dig + index * C->cur->wtree.stride() + cap_off(C->cur->wtree, c.cfg.cap_height); count = cap_words; }
     else if (name == "zs") { src = C->cur->d_zs + index * zc * n; count = (size_t)zc * n; }
     else if (name == "zs_cap") { src = C->cur->ztree.dig + index * C->cur->ztree.stride() + cap_off(C->cur->ztree, c.cfg.cap_height); count = cap_words; }

@@ -167,7 +167,7 @@ inline std::string verify_proof(const Circuit& C, const VerifierData& vd, const 
     std::vector<Query> queries(C.cfg.num_query_rounds);
     for (auto& q : queries) {
         for (int o = 0; o < 4; o++) {
-            std::vector<u64> ev(oracle_cols[o]);
+            std::vector<u64> ev(oracle_cols[o] + (o ? C.salt() : 0));  // blinded oracles carry SALT_SIZE extra leaf elements
             for (auto& v : ev) v = r.r64();
             q.init_evals.push_back(ev);
             q.init_proofs.push_back(r.merkle_proof());
@@ -349,13 +349,15 @@ inline std::string verify_proof(const Circuit& C, const VerifierData& vd, const 
         u64 subgroup_x = mul(MULT_GEN, pow(w_lde, bitrev((u32)x_index, (int)lde_bits)));
         // fri_combine_initial
         std::vector<u64> e0, e1;
+        // unsalted_eval: the salt elements at the end of a blinded leaf take no part in the combination
+        const size_t zc_ = C.num_zs_cols();
         e0.insert(e0.end(), q.init_evals[0].begin(), q.init_evals[0].end());
-        e0.insert(e0.end(), q.init_evals[1].begin(), q.init_evals[1].end());
+        e0.insert(e0.end(), q.init_evals[1].begin(), q.init_evals[1].begin() + C.cfg.num_wires);
         e0.insert(e0.end(), q.init_evals[2].begin(), q.init_evals[2].begin() + nzpp);
-        e0.insert(e0.end(), q.init_evals[3].begin(), q.init_evals[3].end());
-        e0.insert(e0.end(), q.init_evals[2].begin() + nzpp, q.init_evals[2].end());
+        e0.insert(e0.end(), q.init_evals[3].begin(), q.init_evals[3].begin() + C.num_quotient_cols());
+        e0.insert(e0.end(), q.init_evals[2].begin() + nzpp, q.init_evals[2].begin() + zc_);
         e1.insert(e1.end(), q.init_evals[2].begin(), q.init_evals[2].begin() + NC);
-        e1.insert(e1.end(), q.init_evals[2].begin() + nzpp, q.init_evals[2].end());
+        e1.insert(e1.end(), q.init_evals[2].begin() + nzpp, q.init_evals[2].begin() + zc_);
         auto reduce_base = [&](const std::vector<u64>& v) {
             E2 acc = e2(0);
             for (size_t k = v.size(); k-- > 0;) acc = add(mul(acc, fri_alpha), e2(v[k]));

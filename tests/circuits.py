@@ -324,3 +324,32 @@ def feistel_poseidon(pkg, seeds, rounds=32):
         pw.set_target_arr(st, out)
         pws.append(pw)
     return data, pws
+
+
+def zk_gf_2_8_add(pkg, pairs):
+    """test_gf_2_8_add's circuit under standard_recursion_zk_config (the config of aes-gcm/examples/aes_gcm_128.rs:36)."""
+    b = pkg.CircuitBuilder(zero_knowledge=True)
+    lut = b.byte_xor_lut()
+    x, y = b.add_virtual_byte_target_unsafe(), b.add_virtual_byte_target_unsafe()
+    xy = b.gf_2_8_add(lut, x, y)
+    data = b.build()
+    pws = []
+    for a, c in pairs:
+        pw = pkg.PartialWitness()
+        pw.set_byte_target(x, a)
+        pw.set_byte_target(y, c)
+        pw.set_byte_target(xy, a ^ c)
+        pws.append(pw)
+    return data, pws
+
+
+def zk_example_aes_gcm_128(pkg):
+    """aes-gcm/examples/aes_gcm_128.rs: AesGcm128Target<42> in the zk config, key [123;16], plaintext [231;42]."""
+    b = pkg.CircuitBuilder(zero_knowledge=True)
+    t = pkg.AesGcmTarget.build(b, 4, 10, 42, False)
+    data = b.build()
+    key, nonce, pt = bytes([123] * 16), bytes(12), bytes([231] * 42)
+    ct, tag = pkg.native.gcm_encrypt(key, nonce, pt)
+    pw = pkg.PartialWitness()
+    t.set_targets(pw, key, nonce, pt, ct, tag)
+    return data, [pw]

@@ -19,6 +19,7 @@ def lib():
         L.orc_circuit_load.restype, L.orc_circuit_load.argtypes = vp, [C.c_char_p, sz]
         L.orc_circuit_free.argtypes = [vp]
         L.orc_degree_bits.restype, L.orc_degree_bits.argtypes = C.c_uint32, [vp]
+        L.orc_set_zk.argtypes = [vp, C.c_uint64, C.c_uint64]
         L.orc_verifier_data.restype, L.orc_verifier_data.argtypes = sz, [vp, u64p, sz]
         L.orc_prove.restype, L.orc_prove.argtypes = C.c_int, [vp, u64p, u64p, sz, C.c_char_p, sz, C.POINTER(sz), C.c_int]
         L.orc_trace_len.restype, L.orc_trace_len.argtypes = sz, [vp, C.c_char_p]
@@ -64,6 +65,9 @@ class OracleCircuit:
         out = (C.c_uint64 * n)()
         lib().orc_verifier_data(self.h, out, n)
         return list(out)
+
+    def set_zk(self, seed, proof_index):
+        lib().orc_set_zk(self.h, seed, proof_index)
 
     def prove(self, pw_map, trace=False, cap=1 << 22):
         """Returns (status, proof bytes or None)."""

@@ -284,3 +284,22 @@ def test_c_example_over_the_abi(gpu, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "proved and verified" in out.stdout and "status 1" in out.stdout
+
+
+def test_zero_knowledge_config_bit_exact(gpu, orc):
+    """zk config (the reference's examples): blinding rows and salted leaves from the keyed RNG shared with the oracle."""
+    for data, pws in (circuits.zk_gf_2_8_add(gpu, [(5, 9), (200, 100), (0, 255)]), circuits.zk_example_aes_gcm_128(gpu)):
+        oc = orc.OracleCircuit(data.blob)
+        assert data.verifier_data() == oc.verifier_data()
+        data.set_zk_seed(0xC0FFEE)
+        proofs, status = data.prove_batch(pws)
+        assert status == [0] * len(pws)
+        for i, (pw, proof) in enumerate(zip(pws, proofs)):
+            data.verify(proof)
+            oc.set_zk(0xC0FFEE, i)
+            st, ref = oc.prove(pw.map)
+            assert st == 0 and ref == proof
+        again, _ = data.prove_batch(pws)           # the proof counter advanced: fresh blinding
+        assert all(a != b for a, b in zip(again, proofs))
+        for p in again:
+            data.verify(p)

@@ -273,3 +273,26 @@ def test_feistel_poseidon_circuit(pkg, orc):
     bad = dict(pws[0].map)
     bad[list(bad)[-1]] ^= 1
     assert oc.prove(bad)[0] == 1
+
+
+def test_zero_knowledge_config(pkg, orc):
+    """standard_recursion_zk_config: blinding rows enlarge the circuit, leaves of the three blinded oracles carry 4 salt
+    elements, proofs verify, differ from proof to proof, and are reproducible for a given (seed, proof index)."""
+    data, pws = circuits.zk_gf_2_8_add(pkg, [(5, 9)])
+    plain, _ = circuits.gf_2_8_add(pkg, [(5, 9)])
+    assert data.info["degree_bits"] > plain.info["degree_bits"]
+    assert data.proof_bytes > plain.proof_bytes
+    oc = orc.OracleCircuit(data.blob)
+    vd = oc.verifier_data()
+    oc.set_zk(1234, 0)
+    st, p1 = oc.prove(pws[0].map)
+    assert st == 0 and len(p1) == data.proof_bytes
+    data.verify(p1, vd)
+    oc.set_zk(1234, 1)
+    p2 = oc.prove(pws[0].map)[1]
+    data.verify(p2, vd)
+    assert p1 != p2
+    oc.set_zk(1234, 0)
+    assert oc.prove(pws[0].map)[1] == p1
+    with pytest.raises(pkg.P2Error):
+        plain.verify(p1, vd)          # a zk proof is not a proof for the non-zk circuit
