@@ -1,6 +1,6 @@
 /* The reference's canonical entry point (aes-gcm/examples/aes_gcm_128.rs:16-54) over the C ABI, from plain C:
- * build AesGcm128Target<42>, fill the PartialWitness, prove on the GPU, verify.  (The Rust example uses the zk
- * config; this backend implements the non-zk standard_recursion_config used by all 17 circuit tests.)
+ * standard_recursion_zk_config (:36), AesGcm128Target<42>::build (:38), set_targets (:50), prove on the GPU (:52),
+ * verify (:53).
  *   gcc -O2 -Iinclude examples/aes_gcm_128.c -o aes_gcm_128 -Lplonky2-aes_amd -lp2aes -Wl,-rpath,$PWD/plonky2-aes_amd */
 #include <stdio.h>
 #include <stdlib.h>
@@ -15,7 +15,7 @@ int main(void) {
     memset(pt, 231, sizeof pt);
     p2_native_aes_gcm_encrypt(key, 4, 10, nonce, pt, L, ct, tag);
 
-    p2_builder* b = p2_builder_new();
+    p2_builder* b = p2_builder_new_zk(); /* CircuitConfig::standard_recursion_zk_config() */
     p2_target tk[16], tn[12], tp[L], tc[L], tt[16];
     if (p2_aes_gcm_build(b, 4, 10, L, 0, tk, tn, tp, tc, tt)) return fprintf(stderr, "build: %s\n", p2_last_error()), 1;
     printf("AES-GCM-128 (L=%d) num_gates: %zu\n", L, p2_builder_num_gates(b));
