@@ -32,6 +32,34 @@ void orc_circuit_free(void* hp) {
     delete h;
 }
 uint32_t orc_degree_bits(void* hp) { return ((Handle*)hp)->c->degree_bits; }
+// soundness tests: kind 1 = add delta to slot a; kind 2 = add delta to wire cell (column a, row b); kind 0 = off
+void orc_set_fault(void* hp, int kind, uint64_t a, uint64_t b, uint64_t delta) {
+    OCircuit* c = ((Handle*)hp)->c;
+    c->fault_kind = kind;
+    c->fault_a = a;
+    c->fault_b = b;
+    c->fault_delta = delta;
+}
+// structure queries for picking fault sites: gate kind of a row, slot of a routed wire cell, op list
+uint32_t orc_row_gate_kind(void* hp, uint32_t row) {
+    OCircuit* c = ((Handle*)hp)->c;
+    u64 gi = c->constants[(size_t)0 * c->n + row];
+    for (size_t s = 0; s < c->groups.size(); s++) {
+        u64 v = c->constants[s * c->n + row];
+        if (v != 0xFFFFFFFFull) gi = v;
+    }
+    return gi < c->gates.size() ? c->gates[gi] : 0xFFFFFFFFu;
+}
+int32_t orc_wire_slot(void* hp, uint32_t col, uint32_t row) {
+    OCircuit* c = ((Handle*)hp)->c;
+    return (col < c->cfg.num_routed_wires && row < c->n) ? c->wire_slot[(size_t)col * c->n + row] : -1;
+}
+size_t orc_num_ops(void* hp) { return ((Handle*)hp)->c->ops.size(); }
+void orc_get_op(void* hp, size_t i, uint32_t* kind, uint32_t* out) {
+    OCircuit* c = ((Handle*)hp)->c;
+    *kind = c->ops[i].kind;
+    *out = c->ops[i].out;
+}
 // zk circuits: blinding seed and index of the next proof (same keyed RNG as the product)
 void orc_set_zk(void* hp, uint64_t seed, uint64_t proof_index) {
     ((Handle*)hp)->c->zk_seed = seed;

@@ -92,6 +92,10 @@ struct OCircuit {
     std::vector<u32> poseidon_rows, blind_rows;
     std::vector<std::pair<u32, u32>> blind_zrows;
     u64 zk_seed = 0, zk_proof = 0;  // set per proof by the caller (orc_set_zk)
+    // fault injection (soundness tests): after witness generation add `fault_delta` to a slot (every copy of the value:
+    // only gate / lookup constraints can notice) or to one wire cell (the permutation argument must notice)
+    int fault_kind = 0;  // 0 none, 1 slot, 2 wire cell
+    u64 fault_a = 0, fault_b = 0, fault_delta = 0;
     // derived
     size_t n;
     int lde_bits;
@@ -318,6 +322,7 @@ static inline int generate_witness(const OCircuit& C, const u64* in_targets, con
         if (!set(o.out, r)) return 1;
     }
     size_t n = C.n, R = C.cfg.num_routed_wires;
+    if (C.fault_kind == 1 && C.fault_a < C.num_slots && val[C.fault_a] != UNSET) val[C.fault_a] = fadd(val[C.fault_a], C.fault_delta);
     wires.assign(C.cfg.num_wires, std::vector<u64>(n, 0));
     for (size_t c = 0; c < R; c++)
         for (size_t row = 0; row < n; row++) {
@@ -340,6 +345,13 @@ static inline int generate_witness(const OCircuit& C, const u64* in_targets, con
         if (pos_rows[k].empty()) return 2;
         for (size_t c = R; c < C.cfg.num_wires; c++) wires[c][C.poseidon_rows[k]] = pos_rows[k][c];
     }
+    struct FaultAtExit {  // applied to the finished matrix, whatever wrote the cell
+        const OCircuit& C;
+        std::vector<std::vector<u64>>& w;
+        ~FaultAtExit() {
+            if (C.fault_kind == 2 && C.fault_a < w.size() && C.fault_b < C.n) w[C.fault_a][C.fault_b] = fadd(w[C.fault_a][C.fault_b], C.fault_delta);
+        }
+    } fault_at_exit{C, wires};
     // LookupTableGate rows (stored upside down), multiplicities, and padding of the last LookupGate
     // (LookupTableGenerator + prover.rs set_lookup_wires)
     for (size_t l = 0; l < C.luts.size(); l++) {

@@ -353,3 +353,77 @@ def zk_example_aes_gcm_128(pkg):
     pw = pkg.PartialWitness()
     t.set_targets(pw, key, nonce, pt, ct, tag)
     return data, [pw]
+
+
+def random_circuit(pkg, orc, seed, n_ops=60, n_witnesses=2):
+    """A random circuit over the whole builder vocabulary (add / sub / mul / mul_const_add / select / is_equal / S-box
+    lookups / connect / in-circuit Poseidon sponge), evaluated in Python to produce the witnesses; a random subset of the
+    computed targets is asserted in the PartialWitness, the reference's way of checking a circuit."""
+    P = 0xFFFFFFFF00000001
+    S = _sbox(orc)
+    r = random.Random(seed)
+    b = pkg.CircuitBuilder()
+    lut = b.sbox_lut() if r.random() < 0.8 else None
+    n_in = r.randrange(2, 6)
+    nodes = []  # (target, [value per witness], is_byte)
+    inputs = []
+    for _ in range(n_in):
+        byte = lut is not None and r.random() < 0.5
+        t = b.add_virtual_byte_target(lut) if byte else b.add_virtual_target()
+        vals = [r.randrange(256) if byte else r.choice([0, 1, P - 1, r.randrange(P)]) for _ in range(n_witnesses)]
+        nodes.append((t, vals, byte))
+        inputs.append((t, vals))
+    for c in (0, 1, 7, P - 2):
+        nodes.append((b.constant(c), [c] * n_witnesses, c < 256))
+    computed = []
+    for _ in range(n_ops):
+        kind = r.choice(["add", "sub", "mul", "mca", "select", "sbox", "sbox", "connect", "hash"])
+        x, y, z = (r.choice(nodes) for _ in range(3))
+        if kind == "add":
+            t, v, by = b.add(x[0], y[0]), [(a + c) % P for a, c in zip(x[1], y[1])], False
+        elif kind == "sub":
+            t, v, by = b.sub(x[0], y[0]), [(a - c) % P for a, c in zip(x[1], y[1])], False
+        elif kind == "mul":
+            t, v, by = b.mul(x[0], y[0]), [a * c % P for a, c in zip(x[1], y[1])], False
+        elif kind == "mca":
+            k = r.choice([2, 256, P - 1, r.randrange(P)])
+            t, v, by = b.mul_const_add(k, x[0], y[0]), [(k * a + c) % P for a, c in zip(x[1], y[1])], False
+        elif kind == "select":
+            e = b.is_equal(x[0], y[0])
+            ev = [int(a == c) for a, c in zip(x[1], y[1])]
+            nodes.append((e, ev, True))
+            t, v, by = b.select(e, z[0], x[0]), [zz if q else a for q, zz, a in zip(ev, z[1], x[1])], False
+        elif kind == "sbox":
+            bytes_ = [nd for nd in nodes if nd[2]]
+            if lut is None or not bytes_:
+                continue
+            x = r.choice(bytes_)
+            t, v, by = b.add_lookup_from_index(x[0], lut), [S[a] for a in x[1]], True
+        elif kind == "connect":
+            t1, t2 = b.add(x[0], y[0]), b.add(y[0], x[0])
+            if t1 != t2:
+                b.connect(t1, t2)
+            t, v, by = t1, [(a + c) % P for a, c in zip(x[1], y[1])], False
+        else:
+            k = r.randrange(1, 11)
+            ins = [r.choice(nodes) for _ in range(k)]
+            m = r.randrange(1, 10)
+            outs = b.hash_n_to_m_no_pad([nd[0] for nd in ins], m)
+            per_w = [pkg.poseidon_native.hash_n_to_m_no_pad([nd[1][w] for nd in ins], m) for w in range(n_witnesses)]
+            for j, ot in enumerate(outs):
+                nodes.append((ot, [per_w[w][j] for w in range(n_witnesses)], False))
+                computed.append(nodes[-1])
+            continue
+        nodes.append((t, v, by))
+        computed.append(nodes[-1])
+    data = b.build()
+    pws = []
+    asserted = [nd for nd in computed if r.random() < 0.3]
+    for w in range(n_witnesses):
+        pw = pkg.PartialWitness()
+        for t, vals in inputs:
+            pw.set_target(t, vals[w])
+        for t, vals, _ in asserted:
+            pw.set_target(t, vals[w])
+        pws.append(pw)
+    return data, pws

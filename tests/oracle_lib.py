@@ -20,6 +20,11 @@ def lib():
         L.orc_circuit_free.argtypes = [vp]
         L.orc_degree_bits.restype, L.orc_degree_bits.argtypes = C.c_uint32, [vp]
         L.orc_set_zk.argtypes = [vp, C.c_uint64, C.c_uint64]
+        L.orc_set_fault.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.orc_row_gate_kind.restype, L.orc_row_gate_kind.argtypes = C.c_uint32, [vp, C.c_uint32]
+        L.orc_wire_slot.restype, L.orc_wire_slot.argtypes = C.c_int32, [vp, C.c_uint32, C.c_uint32]
+        L.orc_num_ops.restype, L.orc_num_ops.argtypes = sz, [vp]
+        L.orc_get_op.argtypes = [vp, sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.orc_verifier_data.restype, L.orc_verifier_data.argtypes = sz, [vp, u64p, sz]
         L.orc_prove.restype, L.orc_prove.argtypes = C.c_int, [vp, u64p, u64p, sz, C.c_char_p, sz, C.POINTER(sz), C.c_int]
         L.orc_trace_len.restype, L.orc_trace_len.argtypes = sz, [vp, C.c_char_p]
@@ -65,6 +70,23 @@ class OracleCircuit:
         out = (C.c_uint64 * n)()
         lib().orc_verifier_data(self.h, out, n)
         return list(out)
+
+    def set_fault(self, kind, a=0, b=0, delta=1):
+        lib().orc_set_fault(self.h, kind, a, b, delta)
+
+    def row_gate_kind(self, row):
+        return lib().orc_row_gate_kind(self.h, row)
+
+    def wire_slot(self, col, row):
+        return lib().orc_wire_slot(self.h, col, row)
+
+    def ops(self):
+        k, o = C.c_uint32(), C.c_uint32()
+        out = []
+        for i in range(lib().orc_num_ops(self.h)):
+            lib().orc_get_op(self.h, i, C.byref(k), C.byref(o))
+            out.append((k.value, o.value))
+        return out
 
     def set_zk(self, seed, proof_index):
         lib().orc_set_zk(self.h, seed, proof_index)

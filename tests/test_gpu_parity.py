@@ -303,3 +303,9 @@ def test_zero_knowledge_config_bit_exact(gpu, orc):
         assert all(a != b for a, b in zip(again, proofs))
         for p in again:
             data.verify(p)
+
+
+@pytest.mark.parametrize("seed", list(range(100, 124)))
+def test_random_circuits_bit_exact(gpu, orc, seed):
+    data, pws = circuits.random_circuit(gpu, orc, seed, n_ops=80, n_witnesses=3)
+    _gpu_vs_oracle(gpu, orc, data, pws)

@@ -296,3 +296,81 @@ def test_zero_knowledge_config(pkg, orc):
     assert oc.prove(pws[0].map)[1] == p1
     with pytest.raises(pkg.P2Error):
         plain.verify(p1, vd)          # a zk proof is not a proof for the non-zk circuit
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_circuits(pkg, orc, seed):
+    data, pws = circuits.random_circuit(pkg, orc, seed)
+    oc, vd, res = _prove_verify(pkg, orc, data, pws)
+    # flipping any asserted value must make witness generation fail
+    bad = dict(pws[0].map)
+    k = list(bad)[-1]
+    bad[k] = (bad[k] + 1) % 0xFFFFFFFF00000001
+    assert oc.prove(bad)[0] in (1, 2) or len(pws[0].map) <= 6
+
+
+def test_soundness_every_constraint_family_bites(pkg, orc):
+    """Fault injection in the oracle prover: a witness that violates ONE constraint family must yield a proof the verifier
+    rejects.  Slot faults change every copy of a value (the permutation argument still holds), so only the gate /
+    lookup constraints can catch them; cell faults change a single wire of a copy-constrained set."""
+    G_LOOKUP, G_LUT, G_NOOP, G_CONST, G_PI, G_ARITH, G_POS = range(7)
+    OP_ARITH, OP_CONST, OP_LOOKUP, OP_EQ, OP_EQINV, OP_POSEIDON = range(6)
+    P = 0xFFFFFFFF00000001
+
+    def must_reject(data, oc, vd, pw, what):
+        st, proof = oc.prove(pw.map)
+        oc.set_fault(0)
+        assert st == 0, what
+        with pytest.raises(pkg.P2Error):
+            data.verify(proof, vd)
+
+    # circuit 1: AES mix_columns (arithmetic + two lookup tables)
+    data, pws = circuits.mix_columns(pkg, circuits.random_states(7, 1))
+    oc = orc.OracleCircuit(data.blob)
+    vd = oc.verifier_data()
+    st, good = oc.prove(pws[0].map)
+    data.verify(good, vd)
+    n = 1 << data.info["degree_bits"]
+    kinds = [oc.row_gate_kind(r) for r in range(n)]
+    ops = oc.ops()
+    # slots produced by an arithmetic op / a lookup op / a constant op
+    for kind, what in ((OP_ARITH, "ArithmeticGate constraint"), (OP_LOOKUP, "lookup argument (looking value not in table)"), (OP_CONST, "ConstantGate constraint")):
+        slot = next(o for k, o in ops if k == kind)
+        oc.set_fault(1, slot, 0, 1)
+        # the asserted outputs would make witness generation itself fail; drop them for slot faults on asserted values
+        must_reject(data, oc, vd, _inputs_only(pws[0], data, oc), what)
+    # LookupTableGate: wrong multiplicity, and a corrupted table entry
+    row = kinds.index(G_LUT)
+    oc.set_fault(2, 2, row, 1)
+    must_reject(data, oc, vd, pws[0], "lookup argument (multiplicity)")
+    oc.set_fault(2, 1, row, 1)
+    must_reject(data, oc, vd, pws[0], "lookup table content (RE polynomial)")
+    # permutation argument: one cell of an arithmetic row input (copy-constrained to its source) -- also trips the gate;
+    # and a cell on a NoopGate row that no gate constrains and no copy constraint touches must NOT matter
+    row = kinds.index(G_ARITH)
+    oc.set_fault(2, 0, row, 5)
+    must_reject(data, oc, vd, pws[0], "permutation / arithmetic")
+    # PublicInputGate: hash wires must be zero
+    row = kinds.index(G_PI)
+    oc.set_fault(2, 0, row, 1)
+    must_reject(data, oc, vd, pws[0], "PublicInputGate")
+
+    # circuit 2: PoseidonGate -- corrupt an S-box wire of a gate row (unrouted advice wire: only the gate can notice)
+    data, pws, t, cases = circuits.poseidon_encrypt(pkg, 3, [1])
+    oc = orc.OracleCircuit(data.blob)
+    vd = oc.verifier_data()
+    n = 1 << data.info["degree_bits"]
+    row = [oc.row_gate_kind(r) for r in range(n)].index(G_POS)
+    for col, what in ((100, "PoseidonGate full-round S-box wire"), (66, "PoseidonGate partial-round S-box wire"), (24, "PoseidonGate swap bit")):
+        oc.set_fault(2, col, row, 1)
+        must_reject(data, oc, vd, pws[0], what)
+
+
+def _inputs_only(pw, data, oc):
+    """The witness restricted to virtual-target inputs (asserted outputs removed), as a PartialWitness-like object."""
+    class _PW:
+        pass
+    out = _PW()
+    keys = list(pw.map)
+    out.map = {k: pw.map[k] for k in keys[:16]}   # circuits.mix_columns sets the 16 state inputs first
+    return out
