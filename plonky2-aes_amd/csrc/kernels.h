@@ -775,17 +775,36 @@ __global__ void k_lookup_terms(LookupArgs a) {
     const u64* d = a.chal + (size_t)blockIdx.y * CH_WORDS + CH_DELTAS + 4 * ch;  // A, B, Alpha, Delta
     const u64* w = a.wires + (size_t)blockIdx.y * a.wires_batch_stride + row;
     u64 r = 0;
-    if (kind == 1 && k < a.num_sldc) {
-        u32 s1 = min(p2::LUT_SLOTS, (k + 1) * a.lut_deg);
-        for (u32 s = k * a.lut_deg; s < s1; s++) {
-            u64 combo = gl::add(w[(size_t)(3 * s) * a.n], gl::mul(d[0], w[(size_t)(3 * s + 1) * a.n]));
-            r = gl::add(r, gl::mul(w[(size_t)(3 * s + 2) * a.n], gl::inv(gl::sub(d[2], combo))));
+    if ((kind == 1 || kind == 2) && k < a.num_sldc) {
+        // sum over this partial polynomial's slots of c_s / (alpha - combo_s)  (c_s = multiplicity, or -1 for LookupGate
+        // rows) with ONE field inversion: prefix products forwards, peel the inverse backwards (Montgomery's trick)
+        const bool lut = kind == 1;
+        const u32 deg = lut ? a.lut_deg : a.lu_deg, total = lut ? p2::LUT_SLOTS : p2::LU_SLOTS, stride = lut ? 3 : 2;
+        const u32 s0 = k * deg, s1 = min(total, s0 + deg), cnt = s1 > s0 ? s1 - s0 : 0;
+        u64 f[8], pre[8];
+        u64 acc = 1;
+#pragma unroll
+        for (u32 i = 0; i < 8; i++) {  // fixed trip count + predicate keeps f/pre in registers (cnt <= 7)
+            f[i] = 1;
+            pre[i] = acc;
+            if (i < cnt) {
+                u32 s = s0 + i;
+                u64 combo = gl::add(w[(size_t)(stride * s) * a.n], gl::mul(d[0], w[(size_t)(stride * s + 1) * a.n]));
+                f[i] = gl::sub(d[2], combo);
+                acc = gl::mul(acc, f[i]);
+            }
         }
-    } else if (kind == 2 && k < a.num_sldc) {
-        u32 s1 = min(p2::LU_SLOTS, (k + 1) * a.lu_deg);
-        for (u32 s = k * a.lu_deg; s < s1; s++) {
-            u64 combo = gl::add(w[(size_t)(2 * s) * a.n], gl::mul(d[0], w[(size_t)(2 * s + 1) * a.n]));
-            r = gl::sub(r, gl::inv(gl::sub(d[2], combo)));
+        u64 inv_all = gl::inv(acc);
+#pragma unroll
+        for (int i = 7; i >= 0; i--) {
+            if ((u32)i < cnt) {
+                u64 fi_inv = gl::mul(inv_all, pre[i]);
+                inv_all = gl::mul(inv_all, f[i]);
+                if (lut)
+                    r = gl::add(r, gl::mul(w[(size_t)(3 * (s0 + i) + 2) * a.n], fi_inv));
+                else
+                    r = gl::sub(r, fi_inv);
+            }
         }
     } else if (kind == 1) {
         for (u32 s = 0; s < p2::LUT_SLOTS; s++) {

@@ -305,7 +305,7 @@ def test_zero_knowledge_config_bit_exact(gpu, orc):
             data.verify(p)
 
 
-@pytest.mark.parametrize("seed", list(range(100, 124)))
+@pytest.mark.parametrize("seed", list(range(100, 114)))
 def test_random_circuits_bit_exact(gpu, orc, seed):
     data, pws = circuits.random_circuit(gpu, orc, seed, n_ops=80, n_witnesses=3)
     _gpu_vs_oracle(gpu, orc, data, pws)
