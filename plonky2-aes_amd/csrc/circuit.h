@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -228,6 +229,11 @@ static inline Circuit deserialize(const void* data, size_t len) {
     Circuit c;
     r.raw(&c.cfg, sizeof(Config));
     c.degree_bits = r.r32();
+    if (c.degree_bits < 2 || c.degree_bits > 26) throw std::runtime_error("degree_bits out of range");
+    if (c.cfg.num_wires != 135 || c.cfg.num_routed_wires != 80 || c.cfg.num_constants != 2 || c.cfg.num_challenges != 2 ||
+        c.cfg.quotient_degree_factor != 8 || c.cfg.rate_bits != 3 || c.cfg.cap_height != 4 || c.cfg.pow_bits == 0 || c.cfg.pow_bits > 32 ||
+        c.cfg.num_query_rounds == 0 || c.cfg.num_query_rounds > 64 || c.cfg.arity_bits != 4 || c.cfg.final_poly_bits != 5 || c.cfg.zero_knowledge > 1)
+        throw std::runtime_error("unsupported circuit config (only standard_recursion[_zk]_config)");
     r.vec(c.gates);
     r.vec(c.selector_index);
     r.vec(c.groups);
@@ -237,6 +243,7 @@ static inline Circuit deserialize(const void* data, size_t len) {
     r.vec(c.sigmas);
     r.vec(c.k_is);
     u32 nl = r.r32();
+    if (nl > 6) throw std::runtime_error("too many lookup tables");
     c.luts.resize(nl);
     for (auto& l : c.luts) r.vec(l);
     r.vec(c.lookup_rows);
@@ -251,15 +258,39 @@ static inline Circuit deserialize(const void* data, size_t len) {
     r.vec(c.blind_zrows);
     // shape checks: everything a kernel indexes with is validated here, once.
     size_t n = c.n();
-    if (c.degree_bits > 26) throw std::runtime_error("degree_bits too large");
+    if (c.gates.empty() || c.gates.size() > G_NUM_KINDS || c.groups.empty() || c.groups.size() > c.gates.size()) throw std::runtime_error("gate list");
+    for (size_t i = 0; i < c.gates.size(); i++)
+        if (c.gates[i] >= G_NUM_KINDS || (i && c.gates[i] <= c.gates[i - 1])) throw std::runtime_error("gate kinds");
+    for (auto& g : c.groups)
+        if (g.first >= g.second || g.second > c.gates.size()) throw std::runtime_error("selector groups");
+    for (size_t i = 0; i < c.selector_index.size(); i++)
+        if (c.selector_index[i] >= c.groups.size() || i < c.groups[c.selector_index[i]].first || i >= c.groups[c.selector_index[i]].second)
+            throw std::runtime_error("selector index");
+    if (c.num_lookup_selectors != (c.luts.empty() ? 0 : 4 + c.luts.size())) throw std::runtime_error("lookup selector count");
+    {
+        u32 want = 0;
+        for (u32 k : c.gates) want = std::max(want, gate_num_constraints(k));
+        if (c.num_gate_constraints != want) throw std::runtime_error("gate constraint count");
+    }
+    for (auto& l : c.luts)
+        if (l.empty() || l.size() > 65536) throw std::runtime_error("lookup table size");
+    for (size_t i = 1; i < c.level_offsets.size(); i++)
+        if (c.level_offsets[i] < c.level_offsets[i - 1]) throw std::runtime_error("level offsets not monotone");
+    if (!c.level_offsets.empty() && c.level_offsets[0] != 0) throw std::runtime_error("level offsets");
+    for (u64 v : c.k_is)
+        if (v >= 0xFFFFFFFF00000001ull) throw std::runtime_error("non-canonical k_i");
     if (c.constants.size() != (size_t)c.num_constants_cols() * n) throw std::runtime_error("constants shape");
     if (c.sigmas.size() != (size_t)c.cfg.num_routed_wires * n) throw std::runtime_error("sigmas shape");
     if (c.wire_slot.size() != (size_t)c.cfg.num_routed_wires * n) throw std::runtime_error("wire_slot shape");
     if (c.k_is.size() != c.cfg.num_routed_wires) throw std::runtime_error("k_is shape");
     if (c.lookup_rows.size() != c.luts.size() || c.num_lookups.size() != c.luts.size()) throw std::runtime_error("lut shape");
     if (c.selector_index.size() != c.gates.size()) throw std::runtime_error("selector shape");
-    for (auto& lr : c.lookup_rows)
-        if (!(lr.last_lu <= lr.last_lut && lr.last_lut <= lr.first_lut && (size_t)lr.first_lut + 1 < n)) throw std::runtime_error("lookup rows");
+    for (size_t l = 0; l < c.lookup_rows.size(); l++) {
+        auto& lr = c.lookup_rows[l];
+        if (!(lr.last_lu < lr.last_lut && lr.last_lut <= lr.first_lut && (size_t)lr.first_lut + 1 < n)) throw std::runtime_error("lookup rows");
+        if ((size_t)(lr.first_lut - lr.last_lut + 1) != (c.luts[l].size() + LUT_SLOTS - 1) / LUT_SLOTS) throw std::runtime_error("lookup table rows");
+        if ((size_t)(lr.last_lut - lr.last_lu) != ((size_t)c.num_lookups[l] + LU_SLOTS - 1) / LU_SLOTS || c.num_lookups[l] == 0) throw std::runtime_error("lookup gate rows");
+    }
     for (auto& o : c.ops) {
         if (o.out >= c.num_slots) throw std::runtime_error("op out slot");
         if (o.kind == OP_ARITH && (o.a >= c.num_slots || o.b >= c.num_slots || o.c >= c.num_slots)) throw std::runtime_error("op in slot");

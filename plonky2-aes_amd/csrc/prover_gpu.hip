@@ -812,13 +812,13 @@ static void collect_timing(p2_circuit* C) {
     }
     for (auto& pe : all) {
         float ms = 0;
-        hipEventSynchronize(pe.second.second);
-        hipEventElapsedTime(&ms, pe.second.first, pe.second.second);
+        (void)hipEventSynchronize(pe.second.second);
+        (void)hipEventElapsedTime(&ms, pe.second.first, pe.second.second);
         auto& t = C->times[pe.first];
         t.first += ms;
         t.second++;
-        hipEventDestroy(pe.second.first);
-        hipEventDestroy(pe.second.second);
+        (void)hipEventDestroy(pe.second.first);
+        (void)hipEventDestroy(pe.second.second);
     }
 }
 
@@ -910,15 +910,15 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
 
 void p2_circuit_free(p2_circuit* C) {
     if (!C) return;
-    hipSetDevice(C->device);
-    hipDeviceSynchronize();
-    for (void* p : C->allocs) hipFree(p);
+    (void)hipSetDevice(C->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : C->allocs) (void)hipFree(p);
     for (Workspace* W : C->ws) {
-        if (W->stream) hipStreamDestroy(W->stream);
-        if (W->done) hipEventDestroy(W->done);
+        if (W->stream) (void)hipStreamDestroy(W->stream);
+        if (W->done) (void)hipEventDestroy(W->done);
         delete W;
     }
-    if (C->stream) hipStreamDestroy(C->stream);
+    if (C->stream) (void)hipStreamDestroy(C->stream);
     delete C;
 }
 
@@ -1080,9 +1080,9 @@ int p2_prove_batch(p2_circuit* C, size_t batch, const p2_assignment* inputs, uin
                 memset(proofs + i * C->pbytes, 0, C->pbytes);
             }
     }
-    hipFree(d_vals);
-    hipFree(d_proofs);
-    hipFree(d_stat);
+    (void)hipFree(d_vals);
+    (void)hipFree(d_proofs);
+    (void)hipFree(d_stat);
     return rc;
 }
 
@@ -1162,7 +1162,7 @@ int p2_gpu_poseidon(uint64_t* states, size_t n_perm, int device) {
     hipLaunchKernelGGL(k_poseidon_states, g1(n_perm, 256), dim3(256), 0, 0, d, n_perm);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpy(states, d, n_perm * 96, hipMemcpyDeviceToHost));
-    hipFree(d);
+    (void)hipFree(d);
     return P2_OK;
 }
 // A throw-away circuit-less context for the NTT / Merkle primitives
@@ -1201,9 +1201,9 @@ struct PrimCtx {
         return 0;
     }
     ~PrimCtx() {
-        if (C.stream) hipStreamSynchronize(C.stream);
-        for (void* p : C.allocs) hipFree(p);
-        if (C.stream) hipStreamDestroy(C.stream);
+        if (C.stream) (void)hipStreamSynchronize(C.stream);
+        for (void* p : C.allocs) (void)hipFree(p);
+        if (C.stream) (void)hipStreamDestroy(C.stream);
     }
 };
 int p2_gpu_intt(const uint64_t* values, size_t cols, int degree_bits, uint64_t* coeffs, int device) {

@@ -374,3 +374,31 @@ def _inputs_only(pw, data, oc):
     keys = list(pw.map)
     out.map = {k: pw.map[k] for k in keys[:16]}   # circuits.mix_columns sets the 16 state inputs first
     return out
+
+
+def test_blob_mutation_fuzz_never_crashes(pkg):
+    """p2_blob_info (the parser behind p2_circuit_load / p2_verify) on mutated blobs: it may accept or reject, never crash."""
+    import random
+    data, _ = circuits.sub_bytes(pkg, __import__("oracle_lib"), circuits.random_states(1, 1))
+    data2, _, _, _ = circuits.poseidon_encrypt(pkg, 3, [1])
+    info = pkg.api._Info()
+    r = random.Random(0)
+    rejected = 0
+    for blob in (data.blob, data2.blob):
+        n = len(blob)
+        assert pkg.lib().p2_blob_info(blob, n, C.byref(info)) == 0
+        for trial in range(300):
+            b = bytearray(blob)
+            mode = trial % 3
+            if mode == 0:      # flip bytes, mostly in the structured header region
+                for _ in range(r.randrange(1, 4)):
+                    pos = r.randrange(min(n, 400)) if r.random() < 0.7 else r.randrange(n)
+                    b[pos] = r.randrange(256)
+            elif mode == 1:    # truncate
+                b = b[: r.randrange(n)]
+            else:              # overwrite a 4-byte field with an extreme value
+                pos = r.randrange(n - 4)
+                b[pos:pos + 4] = r.choice([b"\xff\xff\xff\xff", b"\x00\x00\x00\x80", b"\xff\xff\xff\x7f"])
+            rc = pkg.lib().p2_blob_info(bytes(b), len(b), C.byref(info))
+            rejected += rc != 0
+    assert rejected > 200
