@@ -165,9 +165,10 @@ int p2_prove_batch(p2_circuit*, size_t batch, const p2_assignment* inputs, uint8
  * d_values: [batch][n_targets] u64 (device pointer), targets shared by the whole batch (host pointer); the value
  * 2^64-1 (not a field element) marks "this witness does not assign the target".
  * d_proofs: device buffer of batch * proof_bytes; d_status: device int[batch].  Asynchronous: kernels are enqueued on
- * the circuit's own streams.  `stream` (a hipStream_t passed as void*) orders the call with the caller: the proving
- * streams wait for the work already enqueued on it and it then waits for the proofs; with NULL the device is
- * synchronised before proving and the caller must call p2_circuit_synchronize() before reading the outputs. */
+ * the circuit's own streams.  `stream` (a hipStream_t passed as void*, NULL = the default stream) orders the call with
+ * the caller: the proving streams wait for the work already enqueued on it and it then waits for the proofs, so work
+ * the caller enqueues on `stream` afterwards sees them.  d_values must stay untouched until then.  Host code calls
+ * p2_circuit_synchronize() (or synchronises `stream`) before reading the outputs. */
 int p2_prove_batch_device(p2_circuit*, size_t batch, const p2_target* targets, size_t n_targets, const uint64_t* d_values,
                           uint8_t* d_proofs, int* d_status, void* stream);
 int p2_circuit_synchronize(p2_circuit*);

@@ -34,6 +34,8 @@ struct Tree {
 struct Workspace {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;  // recorded after the last kernel of a call; the caller's stream waits on it
+    u32* d_input_slots = nullptr;      // slot of every input target, as last uploaded to this workspace
+    std::vector<u32> h_input_slots;    // host copy: re-uploaded only when a call brings a different target list
     u64* d_input_values = nullptr;
     u64* d_values = nullptr;
     u32* d_mult = nullptr;
@@ -95,7 +97,6 @@ struct p2_circuit {
     hipStream_t cur_stream() { return cur ? cur->stream : stream; }
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>>& cur_pending() { return cur ? cur->pending : setup_ws.pending; }
     u32 ws_inputs = 0;
-    u32* d_input_slots = nullptr;
     size_t chunk = 0;
     // timing
     bool timing_on = false;
@@ -453,13 +454,13 @@ static int alloc_workspace(p2_circuit* C, size_t chunk, u32 n_inputs, size_t nst
     C->chunk = chunk;
     C->ws_inputs = std::max<u32>(n_inputs, 1);
     int e = 0;
-    e |= dalloc(C, &C->d_input_slots, C->ws_inputs);
     for (size_t wi = 0; wi < nstreams && !e; wi++) {
     Workspace* W = new Workspace();
     C->ws.push_back(W);
     C->cur = W;
     if (hipStreamCreateWithFlags(&W->stream, hipStreamNonBlocking) != hipSuccess) return set_error("hipStreamCreate failed"), P2_ERR_HIP;
     if (hipEventCreateWithFlags(&W->done, hipEventDisableTiming) != hipSuccess) return set_error("hipEventCreate failed"), P2_ERR_HIP;
+    e |= dalloc(C, &W->d_input_slots, C->ws_inputs);
     e |= dalloc(C, &C->cur->d_input_values, chunk * C->ws_inputs);
     e |= dalloc(C, &C->cur->d_values, chunk * c.num_slots);
     e |= dalloc(C, &C->cur->d_mult, chunk * std::max<size_t>(C->total_lut_entries, 1));
@@ -508,7 +509,7 @@ static int alloc_workspace(p2_circuit* C, size_t chunk, u32 n_inputs, size_t nst
 }
 
 // ---------------------------------------------------------------------------------- the pipeline
-// d_targets_slots already uploaded to C->d_input_slots; d_values: [batch][n_inputs] device; proofs/status: device.
+// the target slots are already in the current workspace (d_input_slots); d_values: [batch][n_inputs] device; proofs/status: device.
 static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, uint8_t* d_proofs, int* d_status_out, u64 proof_base) {
     const Circuit& c = C->c;
     const size_t n = C->n, N = C->N;
@@ -527,7 +528,7 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         a.num_levels = (u32)c.level_offsets.size() - 1;
         a.num_slots = c.num_slots;
         a.n_inputs = n_inputs;
-        a.input_slots = C->d_input_slots;
+        a.input_slots = C->cur->d_input_slots;
         a.input_values = d_values;
         a.values = C->cur->d_values;
         a.lut_idx = C->d_lut_idx;
@@ -990,33 +991,33 @@ int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets,
     size_t chunk = C->chunk ? C->chunk : std::min<size_t>(std::max<size_t>(batch, 1), want_chunk);
     size_t nstreams = C->chunk ? C->ws.size() : std::min(want_streams, (batch + chunk - 1) / chunk);
     if (alloc_workspace(C, chunk, (u32)n_targets, nstreams)) return P2_ERR_HIP;
-    HIPCHECK(hipMemcpy(C->d_input_slots, slots.data(), n_targets * 4, hipMemcpyHostToDevice));
-    // Ordering with the caller: with a stream, the proving streams wait for everything the caller has enqueued on it
-    // (its inputs) and the caller's stream then waits for the proofs; without one, the whole device is synchronised first.
+    // Ordering with the caller: the proving streams wait for everything already enqueued on the caller's stream (its
+    // inputs) and the caller's stream then waits for the proofs.  NULL means the legacy default stream, which is
+    // ordered the same way (an event recorded on stream 0) -- no device-wide synchronisation, so consecutive calls
+    // pipeline into each other.
     hipEvent_t ev_in = nullptr;
-    if (caller) {
-        HIPCHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
-        HIPCHECK(hipEventRecord(ev_in, caller));
-        for (Workspace* W : C->ws) HIPCHECK(hipStreamWaitEvent(W->stream, ev_in, 0));
-    } else {
-        HIPCHECK(hipDeviceSynchronize());
-    }
+    HIPCHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(ev_in, caller));
+    for (Workspace* W : C->ws) HIPCHECK(hipStreamWaitEvent(W->stream, ev_in, 0));
     size_t k = 0;
     for (size_t done = 0; done < batch; done += C->chunk, k++) {
         u32 B = (u32)std::min(C->chunk, batch - done);
         C->cur = C->ws[k % C->ws.size()];
+        if (C->cur->h_input_slots != slots) {  // a new target list: wait for the workspace's earlier chunks, then upload
+            HIPCHECK(hipStreamSynchronize(C->cur->stream));
+            HIPCHECK(hipMemcpy(C->cur->d_input_slots, slots.data(), n_targets * 4, hipMemcpyHostToDevice));
+            C->cur->h_input_slots = slots;
+        }
         int rc = prove_chunk(C, B, (u32)n_targets, d_values + done * n_targets, d_proofs + done * C->pbytes, d_status + done, C->zk_counter + done);
         C->cur = nullptr;
         if (rc) return rc;
     }
     C->zk_counter += batch;
-    if (caller) {
-        for (Workspace* W : C->ws) {
-            HIPCHECK(hipEventRecord(W->done, W->stream));
-            HIPCHECK(hipStreamWaitEvent(caller, W->done, 0));
-        }
-        HIPCHECK(hipEventDestroy(ev_in));
+    for (Workspace* W : C->ws) {
+        HIPCHECK(hipEventRecord(W->done, W->stream));
+        HIPCHECK(hipStreamWaitEvent(caller, W->done, 0));
     }
+    HIPCHECK(hipEventDestroy(ev_in));
     return P2_OK;
 }
 
