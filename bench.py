@@ -44,6 +44,31 @@ def synth_inputs(pkg, target, index, L):
     return pw
 
 
+def synth_elgamal_inputs(pkg, targets, index):
+    """ElGamal workload (BASELINE.json configs[3]; ecgfp5/src/elgamal/circuit.rs:78-96): key, message point and nonce
+    from seeds 0x5EED + 3 i + {0, 1, 2}."""
+    pk_t, nonce_t, msg_t, ct_t = targets
+    E = pkg.ecgfp5
+    sk = pkg.ECGFP5SecretKey.rand(0x5EED + 3 * index)
+    pk, msg, nonce = sk.public_key(), E.new_rand_from_subgroup(0x5EED + 3 * index + 1), E.random_scalar(0x5EED + 3 * index + 2)
+    ct = E.elgamal_encrypt(pk, nonce, msg)
+    pw = pkg.PartialWitness()
+    pw.set_point_target(pk_t, pk)
+    pw.set_point_target(msg_t, msg)
+    pw.set_biguint320_target(nonce_t, nonce)
+    pw.set_point_target(ct_t[0], ct[0])
+    pw.set_point_target(ct_t[1], ct[1])
+    return pw
+
+
+def path_bytes_per_proof(info, live_wires):
+    """bytes/proof = 64 n [4.25 c_w + 4.125 (c_z + c_q) + 2 c_p] + 1536 n with this build's column counts
+    (c_w = wire columns that carry data, c_p = constants + 80 sigmas)."""
+    n = 1 << info["degree_bits"]
+    c_p = info["num_constants_cols"] + info["num_routed_wires"]
+    return 64 * n * (4.25 * live_wires + 4.125 * (info["num_zs_cols"] + info["num_quotient_cols"]) + 2 * c_p) + 1536 * n
+
+
 def kernel_bytes(name, info, active_wires=80):
     """Algorithmic HBM bytes of ONE launch of a kernel, per proof (DESIGN.md 'Kernels')."""
     n = 1 << info["degree_bits"]
@@ -64,6 +89,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=64, help="proofs per step per GPU")
     ap.add_argument("--plaintext-bytes", type=int, default=1024)
+    ap.add_argument("--workload", choices=["aes-gcm", "elgamal"], default="aes-gcm",
+                    help="aes-gcm = BASELINE.json's metric workload (default); elgamal = configs[3]'s circuit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2, help="proofs timed on the host for cpu_baseline")
     args = ap.parse_args()
@@ -89,14 +116,25 @@ def main():
     if L > 4096 and args.batch == 64:
         B = 16  # deep circuits: ~7 GB of workspace per proof -> two chunks of 8, one per stream, so witness generation overlaps
     builder = pkg.CircuitBuilder()
-    target = pkg.AesGcmTarget.build(builder, 4, 10, L, False)  # AesGcm128Target<L>, aes-gcm/src/lib.rs:19
+    if args.workload == "elgamal":
+        pk_t, nonce_t, msg_t = builder.add_virtual_point_target(), builder.add_virtual_biguint320_target(), builder.add_virtual_point_target()
+        target = (pk_t, nonce_t, msg_t, builder.elgamal_encrypt(pk_t, nonce_t, msg_t))
+    else:
+        target = pkg.AesGcmTarget.build(builder, 4, 10, L, False)  # AesGcm128Target<L>, aes-gcm/src/lib.rs:19
     data = pkg.CircuitData(builder.build().blob, device=local_rank)
     info = data.info
     h = data.gpu()
     pb = data.proof_bytes
 
     # synthetic witnesses: rank r proves proofs [r*B, (r+1)*B); inputs are placed in HBM before the timed region
-    pws = [synth_inputs(pkg, target, rank * B + i, L) for i in range(B)]
+    if args.workload == "elgamal":
+        pws = [synth_elgamal_inputs(pkg, target, rank * B + i) for i in range(B)]
+        label = "ecGFp5 ElGamal encryption circuit (elgamal/circuit.rs:28), n=2^%d rows, standard_recursion_config" % info["degree_bits"]
+        metric = "proofs/sec (ElGamal circuit)"
+    else:
+        pws = [synth_inputs(pkg, target, rank * B + i, L) for i in range(B)]
+        label = "AES-GCM-128 %d-byte plaintext circuit (AesGcm128Target<%d>, TAG=false), n=2^%d rows, standard_recursion_config" % (L, L, info["degree_bits"])
+        metric = "proofs/sec (AES-GCM 1 KiB circuit)" if L == 1024 else "proofs/sec (AES-GCM %d B circuit)" % L
     targets = list(pws[0].map.keys())
     nt = len(targets)
     vals = torch.tensor([[pw.map[t] - (1 << 64) if pw.map[t] >= (1 << 63) else pw.map[t] for t in targets] for pw in pws],
@@ -168,7 +206,7 @@ def main():
         try:  # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x2 per calibration, WRITE_SIZE), profiles/
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             key = {"hash_leaves": "k_hash_leaves", "lde": "k_ntt_lds", "quotient": "k_quotient<false>"}.get(dom)
-            if key and L == 1024 and chunk == 32:
+            if key and L == 1024 and chunk == 32 and args.workload == "aes-gcm":
                 traffic = tj["per_launch_avg_bytes"][key].get("total_chunk_launches_only", tj["per_launch_avg_bytes"][key]["total"])
         except Exception:  # noqa: BLE001
             traffic = None
@@ -192,17 +230,21 @@ def main():
         got = bytes(proofs[: args.cpu_sample * pb].cpu().numpy().tobytes())
         assert got[(args.cpu_sample - 1) * pb: args.cpu_sample * pb] == ref, "GPU proof differs from the oracle's"
         cpu_baseline = {"value": round(args.cpu_sample / cdt, 4), "unit": "proofs/s", "cores": oracle_lib.lib().orc_num_threads(),
-                        "kind": "port", "sample": "%d proofs of the same AES-GCM-128 L=%d workload (C++ restatement, OpenMP; not the Rust reference)" % (args.cpu_sample, L)}
+                        "kind": "port", "sample": "%d proofs of the same workload (%s; C++ restatement, OpenMP; not the Rust reference)" % (args.cpu_sample, label.split(",")[0])}
 
     if rank == 0:
         total_proofs = B * args.steps * world
+        pbp = path_bytes_per_proof(info, 80)  # neither workload has Poseidon gates: only the 80 routed wire columns carry data
+        whole_path = {"bytes_per_proof_formula": int(pbp), "achieved_GBps_per_gpu": round(pbp * total_proofs / dt / world / 1e9, 1),
+                      "frac_of_hbm_peak": round(pbp * total_proofs / dt / world / 1e9 / HBM_PEAK_GBS, 4),
+                      "note": "SURVEY.md 8(d) formula with this build's column counts; the path is Poseidon/VALU bound, see roofline.note"}
         out = {
-            "metric": "proofs/sec (AES-GCM 1 KiB circuit)", "value": round(total_proofs / dt, 3), "unit": "proofs/s",
+            "metric": metric, "value": round(total_proofs / dt, 3), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks field)", "data": "synthetic",
-            "config": {"workload": "AES-GCM-128 %d-byte plaintext circuit (AesGcm128Target<%d>, TAG=false), n=2^%d rows, standard_recursion_config"
-                       % (L, L, info["degree_bits"]), "proofs_per_step_per_gpu": B, "proof_bytes": pb, "parallelism": "independent proofs sharded by index"},
+            "config": {"workload": label, "proofs_per_step_per_gpu": B, "proof_bytes": pb, "parallelism": "independent proofs sharded by index"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "whole_path": whole_path,
             "kernels_ms_per_chunk32": {k: round(v[0], 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1][0])},
         }
         print(json.dumps(out))

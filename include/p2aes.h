@@ -119,6 +119,46 @@ void p2_native_hash_n_to_m_no_pad(const uint64_t* in, size_t n, uint64_t* out, s
 void p2_native_poseidon_encrypt(const uint64_t* ks10, const uint64_t* msg, size_t n_msg, const uint64_t* nonce2, uint64_t* ct);
 int p2_native_poseidon_decrypt(const uint64_t* ks10, const uint64_t* ct, size_t n_ct, const uint64_t* nonce2, size_t l, uint64_t* msg);
 
+/* ------------------------------------------------------------------ ecGFp5 / ElGamal (host) */
+/* The curve is pod2's (not in the reference tree; see csrc/ecgfp5.h).  A point is its affine (x, u) coordinates, ten
+ * words, x then u -- pod2 `Point::as_fields` (hashed_elgamal.rs:23); a scalar is five little-endian 64-bit limbs. */
+#define P2_POINT_WORDS 10
+#define P2_SCALAR_LIMBS 5
+#define P2_SCALAR_BITS 320
+void p2_ecgfp5_group_order(uint64_t out[5]);                     /* GROUP_ORDER (lib.rs:12) */
+void p2_ecgfp5_generator(uint64_t out[10]);                      /* Point::generator() */
+void p2_ecgfp5_mul(const uint64_t k[5], const uint64_t p[10], uint64_t out[10]); /* &k * P */
+void p2_ecgfp5_add(const uint64_t p[10], const uint64_t q[10], uint64_t out[10]);
+void p2_ecgfp5_neg(const uint64_t p[10], uint64_t out[10]);      /* Point::inverse (elgamal.rs:21) */
+int p2_ecgfp5_is_in_subgroup(const uint64_t p[10]);              /* 1 / 0 */
+void p2_ecgfp5_compress(const uint64_t p[10], uint64_t w[5]);    /* compress_from_subgroup (lib.rs:82) */
+int p2_ecgfp5_decompress(const uint64_t w[5], uint64_t out[10]); /* decompress_into_subgroup (lib.rs:74); P2_ERR_INVALID if none */
+void p2_ecgfp5_random_scalar(uint64_t seed, uint64_t out[5]);    /* gen_biguint_below(&GROUP_ORDER), seeded (upstream: OsRng) */
+void p2_ecgfp5_random_point(uint64_t seed, uint64_t out[10]);    /* Point::new_rand_from_subgroup, seeded */
+/* encode_binary / decode_binary (lib.rs:48, :80): 160 message bits as five 32-bit limbs */
+void p2_ecgfp5_encode_binary(const uint32_t limbs[5], uint64_t seed, uint64_t out[10]);
+void p2_ecgfp5_decode_binary(const uint64_t p[10], uint32_t limbs[5]);
+/* elgamal.rs:11, :19; hashed_elgamal.rs:19, :28.  Scalars must be below the group order (P2_ERR_INVALID otherwise). */
+int p2_elgamal_encrypt(const uint64_t pk[10], const uint64_t nonce[5], const uint64_t msg[10], uint64_t c0[10], uint64_t c1[10]);
+int p2_elgamal_decrypt(const uint64_t sk[5], const uint64_t c0[10], const uint64_t c1[10], uint64_t msg[10]);
+int p2_hashed_elgamal_encrypt(const uint64_t pk[10], const uint64_t nonce[5], const uint64_t msg[5], uint64_t c0[10], uint64_t ct[5]);
+int p2_hashed_elgamal_decrypt(const uint64_t sk[5], const uint64_t c0[10], const uint64_t ct[5], uint64_t msg[5]);
+/* pod2 CircuitBuilderElliptic / CircuitBuilderBits as the reference calls them (ecgfp5/src/circuit.rs:33-38,
+ * elgamal/circuit.rs:34-37,70-72): points are 10 targets, a BigUInt320Target is its 320 little-endian bit targets. */
+void p2_builder_add_virtual_point_target(p2_builder*, p2_target out[10]);
+void p2_builder_constant_point(p2_builder*, const uint64_t p[10], p2_target out[10]);
+void p2_builder_add_virtual_biguint320_target(p2_builder*, p2_target bits[320]);
+int p2_builder_multiply_point(p2_builder*, const p2_target bits[320], const p2_target p[10], p2_target out[10]);
+void p2_builder_add_point(p2_builder*, const p2_target p[10], const p2_target q[10], p2_target out[10]);
+/* CircuitBuilderECGFP5PublicKey::public_key (ecgfp5/src/circuit.rs:35) */
+int p2_builder_public_key(p2_builder*, const p2_target sk_bits[320], p2_target pk[10]);
+/* CircuitBuilderElGamal::elgamal_encrypt (elgamal/circuit.rs:28) */
+int p2_builder_elgamal_encrypt(p2_builder*, const p2_target pk[10], const p2_target nonce_bits[320], const p2_target msg[10],
+                               p2_target c0[10], p2_target c1[10]);
+/* CircuitBuilderHashedElGamal::hashed_elgamal_encrypt (hashed_elgamal/circuit.rs:33) */
+int p2_builder_hashed_elgamal_encrypt(p2_builder*, const p2_target pk[10], const p2_target nonce_bits[320], const p2_target msg[5],
+                                      p2_target c0[10], p2_target ct[5]);
+
 /* ------------------------------------------------------------------ native cipher (host; witness values) */
 uint8_t p2_native_gf_2_8_mul(uint8_t a, uint8_t b);
 void p2_native_aes_key_expansion(const uint8_t* key, int nk, int nr, uint8_t* out /* 16*(nr+1) */);

@@ -7,10 +7,12 @@ from .api import (  # noqa: F401
     AesGcmTarget,
     CircuitBuilder,
     CircuitData,
+    ECGFP5SecretKey,
     P2Error,
     PartialWitness,
     PoseidonEncryptTarget,
     ProveError,
+    ecgfp5,
     lib,
     lib_path,
     native,

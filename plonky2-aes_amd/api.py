@@ -31,6 +31,9 @@ class ProveError(P2Error):
                           3: "opening point is in the subgroup"}.get(status, "prove failed (%d)" % status))
 
 
+u32p = C.POINTER(C.c_uint32)
+
+
 def lib_path():
     return os.environ.get("P2AES_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libp2aes.so")
 
@@ -96,6 +99,21 @@ def lib():
         "p2_native_hash_n_to_m_no_pad": (None, [u64p, sz, u64p, sz]),
         "p2_native_poseidon_encrypt": (None, [u64p, u64p, sz, u64p, u64p]),
         "p2_native_poseidon_decrypt": (C.c_int, [u64p, u64p, sz, u64p, sz, u64p]),
+        "p2_ecgfp5_group_order": (None, [u64p]), "p2_ecgfp5_generator": (None, [u64p]),
+        "p2_ecgfp5_mul": (None, [u64p, u64p, u64p]), "p2_ecgfp5_add": (None, [u64p, u64p, u64p]), "p2_ecgfp5_neg": (None, [u64p, u64p]),
+        "p2_ecgfp5_is_in_subgroup": (C.c_int, [u64p]),
+        "p2_ecgfp5_compress": (None, [u64p, u64p]), "p2_ecgfp5_decompress": (C.c_int, [u64p, u64p]),
+        "p2_ecgfp5_random_scalar": (None, [u64, u64p]), "p2_ecgfp5_random_point": (None, [u64, u64p]),
+        "p2_ecgfp5_encode_binary": (None, [u32p, u64, u64p]), "p2_ecgfp5_decode_binary": (None, [u64p, u32p]),
+        "p2_elgamal_encrypt": (C.c_int, [u64p, u64p, u64p, u64p, u64p]), "p2_elgamal_decrypt": (C.c_int, [u64p, u64p, u64p, u64p]),
+        "p2_hashed_elgamal_encrypt": (C.c_int, [u64p, u64p, u64p, u64p, u64p]),
+        "p2_hashed_elgamal_decrypt": (C.c_int, [u64p, u64p, u64p, u64p]),
+        "p2_builder_add_virtual_point_target": (None, [vp, u64p]), "p2_builder_constant_point": (None, [vp, u64p, u64p]),
+        "p2_builder_add_virtual_biguint320_target": (None, [vp, u64p]),
+        "p2_builder_multiply_point": (C.c_int, [vp, u64p, u64p, u64p]), "p2_builder_add_point": (None, [vp, u64p, u64p, u64p]),
+        "p2_builder_public_key": (C.c_int, [vp, u64p, u64p]),
+        "p2_builder_elgamal_encrypt": (C.c_int, [vp, u64p, u64p, u64p, u64p, u64p]),
+        "p2_builder_hashed_elgamal_encrypt": (C.c_int, [vp, u64p, u64p, u64p, u64p, u64p]),
         "p2_native_gf_2_8_mul": (C.c_uint8, [C.c_uint8, C.c_uint8]),
         "p2_native_aes_key_expansion": (None, [C.c_char_p, C.c_int, C.c_int, C.c_char_p]),
         "p2_native_aes_encrypt_block": (None, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p]),
@@ -244,6 +262,54 @@ class CircuitBuilder:
             raise P2Error(_err())
         return list(out)
 
+    # ---- pod2 CircuitBuilderElliptic / CircuitBuilderBits and the ecgfp5 crate's builder traits.  A PointTarget is its ten
+    # targets (x then u), a BigUInt320Target its 320 little-endian bit targets.
+    def add_virtual_point_target(self):
+        out = (u64 * 10)()
+        lib().p2_builder_add_virtual_point_target(self._h, out)
+        return list(out)
+
+    def constant_point(self, point):
+        out = (u64 * 10)()
+        lib().p2_builder_constant_point(self._h, _pt(point), out)
+        return list(out)
+
+    def add_virtual_biguint320_target(self):
+        out = (u64 * 320)()
+        lib().p2_builder_add_virtual_biguint320_target(self._h, out)
+        return list(out)
+
+    def multiply_point(self, bits, point_target):
+        out = (u64 * 10)()
+        if lib().p2_builder_multiply_point(self._h, _arr(bits), _arr(point_target), out):
+            raise P2Error(_err())
+        return list(out)
+
+    def add_point(self, p, q):
+        out = (u64 * 10)()
+        lib().p2_builder_add_point(self._h, _arr(p), _arr(q), out)
+        return list(out)
+
+    def add_secret_key(self): return self.add_virtual_biguint320_target()   # ecgfp5/src/circuit.rs:31
+
+    def public_key(self, sk_target):                                         # ecgfp5/src/circuit.rs:35
+        out = (u64 * 10)()
+        if lib().p2_builder_public_key(self._h, _arr(sk_target), out):
+            raise P2Error(_err())
+        return list(out)
+
+    def elgamal_encrypt(self, pk, nonce, msg):                               # elgamal/circuit.rs:28
+        c0, c1 = (u64 * 10)(), (u64 * 10)()
+        if lib().p2_builder_elgamal_encrypt(self._h, _arr(pk), _arr(nonce), _arr(msg), c0, c1):
+            raise P2Error(_err())
+        return list(c0), list(c1)
+
+    def hashed_elgamal_encrypt(self, pk, nonce, msg):                        # hashed_elgamal/circuit.rs:33
+        c0, ct = (u64 * 10)(), (u64 * 5)()
+        if lib().p2_builder_hashed_elgamal_encrypt(self._h, _arr(pk), _arr(nonce), _arr(msg), c0, ct):
+            raise P2Error(_err())
+        return list(c0), list(ct)
+
     def build(self):
         blob, n = u8p(), sz()
         if lib().p2_builder_build(self._h, C.byref(blob), C.byref(n)):
@@ -273,6 +339,16 @@ class PartialWitness:
             self.set_target(t, v)
 
     # PartialWitnessByteArray / PartialWitnessAESState (circuit_aes.rs:277-297)
+    def set_point_target(self, target, point):            # pod2 WitnessWriteCurve (elgamal/circuit.rs:88-92)
+        self.set_target_arr(target, list(point[0]) + list(point[1]))
+
+    def set_biguint320_target(self, target, value):       # pod2 bits (elgamal/circuit.rs:90)
+        assert 0 <= value < 1 << 320
+        self.set_target_arr(target, [(value >> i) & 1 for i in range(320)])
+
+    def set_secret_key_target(self, target, sk):          # ecgfp5/src/circuit.rs:52
+        self.set_biguint320_target(target, sk.value)
+
     def set_byte_target(self, target, value): self.set_target(target, value & 0xFF if isinstance(value, int) else int(value))
     def set_state_target(self, targets, state16):
         for t, v in zip(targets, state16):
@@ -436,6 +512,135 @@ class poseidon_native:
         if lib().p2_native_poseidon_decrypt(_arr([v for fq in ks for v in fq]), _arr([v for fq in ct for v in fq]), len(ct), _arr(nonce), l, msg):
             raise P2Error(_err())
         return [tuple(msg[5 * i:5 * i + 5]) for i in range(l)]
+
+
+def _pt(point):
+    return _arr(list(point[0]) + list(point[1]))
+
+
+def _pt_out(buf):
+    return (tuple(buf[0:5]), tuple(buf[5:10]))
+
+
+def _sc(k):
+    return _arr([(k >> (64 * i)) & (2**64 - 1) for i in range(5)])
+
+
+class ecgfp5:
+    """The ecgfp5 crate's native side (ecgfp5/src/lib.rs, elgamal.rs, hashed_elgamal.rs) through the C ABI.  A Point is
+    ((x0..x4), (u0..u4)); scalars are Python ints.  Randomness takes an explicit seed where upstream reads OsRng."""
+
+    @staticmethod
+    def group_order():
+        out = (u64 * 5)()
+        lib().p2_ecgfp5_group_order(out)
+        return sum(int(out[i]) << (64 * i) for i in range(5))
+
+    @staticmethod
+    def generator():
+        out = (u64 * 10)()
+        lib().p2_ecgfp5_generator(out)
+        return _pt_out(out)
+
+    @staticmethod
+    def mul(k, point):
+        out = (u64 * 10)()
+        lib().p2_ecgfp5_mul(_sc(k), _pt(point), out)
+        return _pt_out(out)
+
+    @staticmethod
+    def add(p, q):
+        out = (u64 * 10)()
+        lib().p2_ecgfp5_add(_pt(p), _pt(q), out)
+        return _pt_out(out)
+
+    @staticmethod
+    def neg(p):
+        out = (u64 * 10)()
+        lib().p2_ecgfp5_neg(_pt(p), out)
+        return _pt_out(out)
+
+    @staticmethod
+    def is_in_subgroup(p): return bool(lib().p2_ecgfp5_is_in_subgroup(_pt(p)))
+
+    @staticmethod
+    def compress_from_subgroup(p):
+        out = (u64 * 5)()
+        lib().p2_ecgfp5_compress(_pt(p), out)
+        return tuple(out)
+
+    @staticmethod
+    def decompress_into_subgroup(w):
+        out = (u64 * 10)()
+        if lib().p2_ecgfp5_decompress(_arr(list(w)), out):
+            raise P2Error(_err())
+        return _pt_out(out)
+
+    @staticmethod
+    def random_scalar(seed):
+        out = (u64 * 5)()
+        lib().p2_ecgfp5_random_scalar(seed, out)
+        return sum(int(out[i]) << (64 * i) for i in range(5))
+
+    @staticmethod
+    def new_rand_from_subgroup(seed):
+        out = (u64 * 10)()
+        lib().p2_ecgfp5_random_point(seed, out)
+        return _pt_out(out)
+
+    @staticmethod
+    def encode_binary(x, seed):                            # lib.rs:48
+        assert 0 <= x < 1 << 160
+        out = (u64 * 10)()
+        lib().p2_ecgfp5_encode_binary((C.c_uint32 * 5)(*[(x >> (32 * i)) & 0xFFFFFFFF for i in range(5)]), seed, out)
+        return _pt_out(out)
+
+    @staticmethod
+    def decode_binary(p):                                  # lib.rs:80
+        out = (C.c_uint32 * 5)()
+        lib().p2_ecgfp5_decode_binary(_pt(p), out)
+        return sum(int(out[i]) << (32 * i) for i in range(5))
+
+    @staticmethod
+    def elgamal_encrypt(pk, nonce, msg):                   # elgamal.rs:11
+        c0, c1 = (u64 * 10)(), (u64 * 10)()
+        if lib().p2_elgamal_encrypt(_pt(pk), _sc(nonce), _pt(msg), c0, c1):
+            raise P2Error(_err())
+        return _pt_out(c0), _pt_out(c1)
+
+    @staticmethod
+    def elgamal_decrypt(sk, ct):                           # elgamal.rs:19
+        out = (u64 * 10)()
+        if lib().p2_elgamal_decrypt(_sc(sk.value), _pt(ct[0]), _pt(ct[1]), out):
+            raise P2Error(_err())
+        return _pt_out(out)
+
+    @staticmethod
+    def hashed_elgamal_encrypt(pk, nonce, msg):            # hashed_elgamal.rs:19
+        c0, ct = (u64 * 10)(), (u64 * 5)()
+        if lib().p2_hashed_elgamal_encrypt(_pt(pk), _sc(nonce), _arr(list(msg)), c0, ct):
+            raise P2Error(_err())
+        return _pt_out(c0), tuple(ct)
+
+    @staticmethod
+    def hashed_elgamal_decrypt(sk, ct):                    # hashed_elgamal.rs:28
+        out = (u64 * 5)()
+        if lib().p2_hashed_elgamal_decrypt(_sc(sk.value), _pt(ct[0]), _arr(list(ct[1])), out):
+            raise P2Error(_err())
+        return tuple(out)
+
+
+class ECGFP5SecretKey:
+    """ecgfp5/src/lib.rs:23-42."""
+
+    def __init__(self, s):
+        assert 0 <= s < ecgfp5.group_order()
+        self.value = s
+
+    @staticmethod
+    def rand(seed): return ECGFP5SecretKey(ecgfp5.random_scalar(seed))
+
+    def public_key(self): return ecgfp5.mul(self.value, ecgfp5.generator())
 
 
 class native:

@@ -124,6 +124,14 @@ class CircuitBuilder {
         return equal;
     }
 
+    // 1/x (plonky2 gadgets/arithmetic.rs `inverse`): a hinted value checked by x * inv = 1; x = 0 has no witness
+    Target inverse(Target x) {
+        Target inv = add_virtual_target();
+        gens_.push_back(Gen{OP_EQINV, inv, x, zero(), 0, 0, 0, 0});
+        connect(mul(x, inv), one());
+        return inv;
+    }
+
     // ---- lookups (plonky2 gadgets/lookup.rs) ------------------------------------------------------
     size_t add_lookup_table_from_pairs(const std::vector<std::pair<u16, u16>>& table) {
         for (size_t i = 0; i < luts_.size(); i++)

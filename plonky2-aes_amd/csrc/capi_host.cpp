@@ -5,6 +5,7 @@
 #include "../../include/p2aes.h"
 #include "aes_gadgets.h"
 #include "capi_common.h"
+#include "ecgfp5.h"
 #include "poseidon_cipher.h"
 #include "verifier.h"
 
@@ -214,6 +215,134 @@ int p2_native_poseidon_decrypt(const uint64_t* ks, const uint64_t* ct, size_t n_
     if (n_ct < 1 || l > n_ct - 1 || !pcipher::decrypt(fq_at(ks), fq_at(ks + 5), c, nonce, l, &m)) return set_error("poseidon decrypt: authentication failed"), P2_ERR_VERIFY;
     for (size_t i = 0; i < m.size(); i++) memcpy(msg + 5 * i, m[i].data(), 40);
     return P2_OK;
+}
+
+// ---- ecGFp5
+static ecgfp5::Affine pt_at(const uint64_t* p) { return ecgfp5::Affine{fq_at(p), fq_at(p + 5)}; }
+static void pt_put(const ecgfp5::Affine& a, uint64_t* out) {
+    memcpy(out, a.x.data(), 40);
+    memcpy(out + 5, a.u.data(), 40);
+}
+static ecgfp5::U320 sc_at(const uint64_t* k) {
+    ecgfp5::U320 s;
+    memcpy(s.w, k, 40);
+    return s;
+}
+static void ptt_put(const ecgfp5::PointTarget& p, p2_target* out) {
+    for (int i = 0; i < 5; i++) out[i] = p.x[i], out[5 + i] = p.u[i];
+}
+static ecgfp5::PointTarget ptt_at(const p2_target* p) {
+    ecgfp5::PointTarget t;
+    for (int i = 0; i < 5; i++) t.x[i] = p[i], t.u[i] = p[5 + i];
+    return t;
+}
+static std::vector<BoolTarget> bits_at(const p2_target* bits) {
+    std::vector<BoolTarget> v(ecgfp5::SCALAR_BITS);
+    for (size_t i = 0; i < v.size(); i++) v[i] = BoolTarget{bits[i]};
+    return v;
+}
+static int scalar_ok(const uint64_t* k) {
+    if (!ecgfp5::u320_lt(sc_at(k), ecgfp5::GROUP_ORDER)) return set_error("scalar is not below the group order"), P2_ERR_INVALID;
+    return P2_OK;
+}
+void p2_ecgfp5_group_order(uint64_t out[5]) { memcpy(out, ecgfp5::GROUP_ORDER.w, 40); }
+void p2_ecgfp5_generator(uint64_t out[10]) { pt_put(ecgfp5::generator(), out); }
+void p2_ecgfp5_mul(const uint64_t k[5], const uint64_t p[10], uint64_t out[10]) { pt_put(ecgfp5::scalar_mul(sc_at(k), pt_at(p)), out); }
+void p2_ecgfp5_add(const uint64_t p[10], const uint64_t q[10], uint64_t out[10]) { pt_put(ecgfp5::point_add(pt_at(p), pt_at(q)), out); }
+void p2_ecgfp5_neg(const uint64_t p[10], uint64_t out[10]) { pt_put(ecgfp5::point_neg(pt_at(p)), out); }
+int p2_ecgfp5_is_in_subgroup(const uint64_t p[10]) { return ecgfp5::is_in_subgroup(pt_at(p)) ? 1 : 0; }
+void p2_ecgfp5_compress(const uint64_t p[10], uint64_t w[5]) { memcpy(w, ecgfp5::compress_from_subgroup(pt_at(p)).data(), 40); }
+int p2_ecgfp5_decompress(const uint64_t w[5], uint64_t out[10]) {
+    ecgfp5::Affine a;
+    if (!ecgfp5::decompress_into_subgroup(fq_at(w), &a)) return set_error("not the encoding of a group element"), P2_ERR_INVALID;
+    pt_put(a, out);
+    return P2_OK;
+}
+void p2_ecgfp5_random_scalar(uint64_t seed, uint64_t out[5]) {
+    ecgfp5::SplitMix rng{seed};
+    memcpy(out, ecgfp5::random_scalar(rng).w, 40);
+}
+void p2_ecgfp5_random_point(uint64_t seed, uint64_t out[10]) {
+    ecgfp5::SplitMix rng{seed};
+    pt_put(ecgfp5::random_point(rng), out);
+}
+void p2_ecgfp5_encode_binary(const uint32_t limbs[5], uint64_t seed, uint64_t out[10]) {
+    ecgfp5::SplitMix rng{seed};
+    pt_put(ecgfp5::encode_binary(limbs, rng), out);
+}
+void p2_ecgfp5_decode_binary(const uint64_t p[10], uint32_t limbs[5]) { ecgfp5::decode_binary(pt_at(p), limbs); }
+int p2_elgamal_encrypt(const uint64_t pk[10], const uint64_t nonce[5], const uint64_t msg[10], uint64_t c0[10], uint64_t c1[10]) {
+    if (scalar_ok(nonce)) return P2_ERR_INVALID;
+    ecgfp5::Affine a, b;
+    ecgfp5::elgamal_encrypt(pt_at(pk), sc_at(nonce), pt_at(msg), &a, &b);
+    pt_put(a, c0);
+    pt_put(b, c1);
+    return P2_OK;
+}
+int p2_elgamal_decrypt(const uint64_t sk[5], const uint64_t c0[10], const uint64_t c1[10], uint64_t msg[10]) {
+    if (scalar_ok(sk)) return P2_ERR_INVALID;
+    pt_put(ecgfp5::elgamal_decrypt(sc_at(sk), pt_at(c0), pt_at(c1)), msg);
+    return P2_OK;
+}
+int p2_hashed_elgamal_encrypt(const uint64_t pk[10], const uint64_t nonce[5], const uint64_t msg[5], uint64_t c0[10], uint64_t ct[5]) {
+    if (scalar_ok(nonce)) return P2_ERR_INVALID;
+    ecgfp5::Affine a;
+    ecgfp5::hashed_elgamal_encrypt(pt_at(pk), sc_at(nonce), msg, &a, ct);
+    pt_put(a, c0);
+    return P2_OK;
+}
+int p2_hashed_elgamal_decrypt(const uint64_t sk[5], const uint64_t c0[10], const uint64_t ct[5], uint64_t msg[5]) {
+    if (scalar_ok(sk)) return P2_ERR_INVALID;
+    ecgfp5::hashed_elgamal_decrypt(sc_at(sk), pt_at(c0), ct, msg);
+    return P2_OK;
+}
+void p2_builder_add_virtual_point_target(p2_builder* b, p2_target out[10]) { ptt_put(ecgfp5::add_virtual_point_target(b->b), out); }
+void p2_builder_constant_point(p2_builder* b, const uint64_t p[10], p2_target out[10]) { ptt_put(ecgfp5::constant_point(b->b, pt_at(p)), out); }
+void p2_builder_add_virtual_biguint320_target(p2_builder* b, p2_target bits[320]) {
+    auto v = ecgfp5::add_virtual_biguint320_target(b->b);
+    for (size_t i = 0; i < v.size(); i++) bits[i] = v[i].target;
+}
+int p2_builder_multiply_point(p2_builder* b, const p2_target bits[320], const p2_target p[10], p2_target out[10]) {
+    try {
+        ptt_put(ecgfp5::multiply_point(b->b, bits_at(bits), ptt_at(p)), out);
+        return P2_OK;
+    } catch (std::exception& e) {
+        return set_error(e.what()), P2_ERR_INVALID;
+    }
+}
+void p2_builder_add_point(p2_builder* b, const p2_target p[10], const p2_target q[10], p2_target out[10]) {
+    ptt_put(ecgfp5::add_point(b->b, ptt_at(p), ptt_at(q)), out);
+}
+int p2_builder_public_key(p2_builder* b, const p2_target sk_bits[320], p2_target pk[10]) {
+    try {
+        ptt_put(ecgfp5::public_key_target(b->b, bits_at(sk_bits)), pk);
+        return P2_OK;
+    } catch (std::exception& e) {
+        return set_error(e.what()), P2_ERR_INVALID;
+    }
+}
+int p2_builder_elgamal_encrypt(p2_builder* b, const p2_target pk[10], const p2_target nonce_bits[320], const p2_target msg[10], p2_target c0[10],
+                               p2_target c1[10]) {
+    try {
+        ecgfp5::PointTarget a, c;
+        ecgfp5::elgamal_encrypt_target(b->b, ptt_at(pk), bits_at(nonce_bits), ptt_at(msg), &a, &c);
+        ptt_put(a, c0);
+        ptt_put(c, c1);
+        return P2_OK;
+    } catch (std::exception& e) {
+        return set_error(e.what()), P2_ERR_INVALID;
+    }
+}
+int p2_builder_hashed_elgamal_encrypt(p2_builder* b, const p2_target pk[10], const p2_target nonce_bits[320], const p2_target msg[5],
+                                      p2_target c0[10], p2_target ct[5]) {
+    try {
+        ecgfp5::PointTarget a;
+        ecgfp5::hashed_elgamal_encrypt_target(b->b, ptt_at(pk), bits_at(nonce_bits), msg, &a, ct);
+        ptt_put(a, c0);
+        return P2_OK;
+    } catch (std::exception& e) {
+        return set_error(e.what()), P2_ERR_INVALID;
+    }
 }
 
 // ---- native cipher

@@ -427,3 +427,78 @@ def random_circuit(pkg, orc, seed, n_ops=60, n_witnesses=2):
             pw.set_target(t, vals[w])
         pws.append(pw)
     return data, pws
+
+
+# ---- ecgfp5 crate: the three circuit tests (inputs seeded where upstream draws from OsRng) -------------------------
+def ecgfp5_public_key(pkg, seeds):
+    """ecgfp5/src/circuit.rs:83-100 public_key_calculation."""
+    b = pkg.CircuitBuilder()
+    sk_t = b.add_secret_key()
+    pk_t = b.public_key(sk_t)
+    data = b.build()
+    pws, cases = [], []
+    for seed in seeds:
+        sk = pkg.ECGFP5SecretKey.rand(seed)
+        pk = sk.public_key()
+        pw = pkg.PartialWitness()
+        pw.set_secret_key_target(sk_t, sk)
+        pw.set_point_target(pk_t, pk)
+        pws.append(pw)
+        cases.append((sk, pk))
+    return data, pws, (sk_t, pk_t), cases
+
+
+def ecgfp5_elgamal(pkg, seeds):
+    """ecgfp5/src/elgamal/circuit.rs:65-97 elgamal_encryption."""
+    E = pkg.ecgfp5
+    b = pkg.CircuitBuilder()
+    pk_t = b.add_virtual_point_target()
+    nonce_t = b.add_virtual_biguint320_target()
+    msg_t = b.add_virtual_point_target()
+    ct_t = b.elgamal_encrypt(pk_t, nonce_t, msg_t)
+    data = b.build()
+    pws, cases = [], []
+    for seed in seeds:
+        sk = pkg.ECGFP5SecretKey.rand(3 * seed)
+        pk = sk.public_key()
+        msg = E.new_rand_from_subgroup(3 * seed + 1)
+        nonce = E.random_scalar(3 * seed + 2)
+        ct = E.elgamal_encrypt(pk, nonce, msg)
+        pw = pkg.PartialWitness()
+        pw.set_point_target(pk_t, pk)
+        pw.set_point_target(msg_t, msg)
+        pw.set_biguint320_target(nonce_t, nonce)
+        pw.set_point_target(ct_t[0], ct[0])
+        pw.set_point_target(ct_t[1], ct[1])
+        pws.append(pw)
+        cases.append((sk, pk, msg, nonce, ct))
+    return data, pws, (pk_t, nonce_t, msg_t, ct_t), cases
+
+
+def ecgfp5_hashed_elgamal(pkg, seeds):
+    """ecgfp5/src/hashed_elgamal/circuit.rs:76-107 hashed_elgamal_encryption."""
+    P = 0xFFFFFFFF00000001
+    E = pkg.ecgfp5
+    b = pkg.CircuitBuilder()
+    pk_t = b.add_virtual_point_target()
+    nonce_t = b.add_virtual_biguint320_target()
+    msg_t = b.add_virtual_target_arr(5)
+    ct_t = b.hashed_elgamal_encrypt(pk_t, nonce_t, msg_t)
+    data = b.build()
+    pws, cases = [], []
+    for seed in seeds:
+        r = random.Random(seed)
+        sk = pkg.ECGFP5SecretKey.rand(3 * seed)
+        pk = sk.public_key()
+        msg = tuple(r.randrange(P) for _ in range(5))
+        nonce = E.random_scalar(3 * seed + 2)
+        ct = E.hashed_elgamal_encrypt(pk, nonce, msg)
+        pw = pkg.PartialWitness()
+        pw.set_point_target(pk_t, pk)
+        pw.set_target_arr(msg_t, msg)
+        pw.set_biguint320_target(nonce_t, nonce)
+        pw.set_point_target(ct_t[0], ct[0])
+        pw.set_target_arr(ct_t[1], ct[1])
+        pws.append(pw)
+        cases.append((sk, pk, msg, nonce, ct))
+    return data, pws, (pk_t, nonce_t, msg_t, ct_t), cases
