@@ -499,6 +499,15 @@ class poseidon_native:
         return list(out)
 
     @staticmethod
+    def new_key(seed):                                     # lib.rs:31 (seeded; upstream OsRng)
+        k = ecgfp5.random_scalar(seed)
+        return k, ecgfp5.mul(k, ecgfp5.generator())
+
+    @staticmethod
+    def expanded_key(K, seed):                             # lib.rs:36
+        return ecgfp5.mul(ecgfp5.random_scalar(seed), K)
+
+    @staticmethod
     def encrypt(ks, msg, nonce):
         n = len(msg)
         nct = (n + 2) // 3 * 3 + 1

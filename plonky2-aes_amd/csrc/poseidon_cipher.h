@@ -3,7 +3,7 @@
 // poseidon-cipher/src/circuit.rs (PoseidonEncryptTarget::build :49-89, hash_state_target :121-125).
 // pod2's PointTarget / OEFTarget<5> are not in the reference tree: a point is taken as its two Fq coordinates (x, u)
 // = 10 virtual targets with no curve-membership constraint, and nnf_add is the component-wise addition of an optimal
-// extension field.  Key generation (new_key / expanded_key: EC scalar multiplication in pod2) is out of scope.
+// extension field.  Key generation (new_key / expanded_key, lib.rs:31-39) is a scalar multiplication: see ecgfp5.h.
 #pragma once
 #include <array>
 

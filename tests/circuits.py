@@ -260,8 +260,8 @@ def arithmetic_only(pkg, inputs):
 
 def poseidon_encrypt(pkg, L, seeds):
     """poseidon-cipher/src/circuit.rs:156-190 test body: random key point coordinates (x, u), message of L Fq elements,
-    two nonce elements; expected ciphertext from the native cipher.  (Key generation is pod2 EC arithmetic -- out of scope;
-    the shared-secret point is taken as two arbitrary Fq coordinates.)"""
+    two nonce elements; expected ciphertext from the native cipher.  (The cipher never uses the group structure of the key
+    point, so two arbitrary Fq coordinates exercise the same circuit; tests/test_ecgfp5.py runs it with a real key.)"""
     P = 0xFFFFFFFF00000001
     b = pkg.CircuitBuilder()
     t = pkg.PoseidonEncryptTarget.build(b, L)

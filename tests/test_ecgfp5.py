@@ -119,6 +119,28 @@ def test_elgamal_round_trip(pkg):
         E.elgamal_encrypt(pk, ec.GROUP_ORDER, msg)  # elgamal.rs:12 assert!(nonce < &GROUP_ORDER)
 
 
+def test_poseidon_cipher_with_curve_keys(pkg, orc):
+    # poseidon-cipher/src/lib.rs:141-156 and circuit.rs:156-190: the key really is a group element (new_key, expanded_key)
+    from test_host_logic import _prove_verify
+    r = random.Random(17)
+    k, K = pkg.poseidon_native.new_key(1)
+    assert K == ec.g_mul(k, ec.generator())
+    ks = pkg.poseidon_native.expanded_key(K, 2)
+    assert ec.in_group(ks)
+    nonce = [r.randrange(P), r.randrange(P)]
+    for n in (9, 10, 11):
+        msg = [tuple(r.randrange(P) for _ in range(5)) for _ in range(n)]
+        ct = pkg.poseidon_native.encrypt(ks, msg, nonce)
+        assert pkg.poseidon_native.decrypt(ks, ct, nonce, n) == msg and msg != ct[:n]
+    b = pkg.CircuitBuilder()
+    t = pkg.PoseidonEncryptTarget.build(b, 3)
+    data = b.build()
+    msg = [tuple(r.randrange(P) for _ in range(5)) for _ in range(3)]
+    pw = pkg.PartialWitness()
+    t.set_targets(pw, list(ks), msg, nonce, pkg.poseidon_native.encrypt(ks, msg, nonce))
+    _prove_verify(pkg, orc, data, [pw])
+
+
 def _flip(point):
     return (point[0], (point[1][0] ^ 1,) + tuple(point[1][1:]))
 
