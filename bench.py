@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="proofs per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="proofs per step per GPU (two chunks, one per proving stream)")
     ap.add_argument("--plaintext-bytes", type=int, default=1024)
     ap.add_argument("--workload", choices=["aes-gcm", "elgamal"], default="aes-gcm",
                     help="aes-gcm = BASELINE.json's metric workload (default); elgamal = configs[3]'s circuit")
@@ -113,7 +113,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     L, B = args.plaintext_bytes, args.batch
-    if L > 4096 and args.batch == 64:
+    if L > 4096 and args.batch == 256:
         B = 16  # deep circuits: ~7 GB of workspace per proof -> two chunks of 8, one per stream, so witness generation overlaps
     builder = pkg.CircuitBuilder()
     if args.workload == "elgamal":
@@ -181,7 +181,7 @@ def main():
     kernels = {}
     if rank == 0:
         lib.p2_circuit_set_timing(h, 1)
-        chunk = min(B, 32)
+        chunk = (B + 1) // 2  # the size of the chunks the timed steps ran (B proofs over two streams)
         rc = lib.p2_prove_batch_device(h, chunk, tarr, nt, vals.data_ptr(), proofs.data_ptr(), status.data_ptr(), torch_stream)  # one chunk = one stream
         assert rc == 0
         sync()
@@ -206,8 +206,9 @@ def main():
         try:  # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x2 per calibration, WRITE_SIZE), profiles/
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             key = {"hash_leaves": "k_hash_leaves", "lde": "k_ntt_lds", "quotient": "k_quotient<false>"}.get(dom)
-            if key and L == 1024 and chunk == 32 and args.workload == "aes-gcm":
-                traffic = tj["per_launch_avg_bytes"][key].get("total_chunk_launches_only", tj["per_launch_avg_bytes"][key]["total"])
+            if key and L == 1024 and chunk == tj.get("chunk") and args.workload == "aes-gcm":
+                ent = tj["per_launch_avg_bytes"][key]
+                traffic = ent.get("chunk_launches_avg", ent["total"])
         except Exception:  # noqa: BLE001
             traffic = None
         if nbytes:
@@ -245,7 +246,7 @@ def main():
             "config": {"workload": label, "proofs_per_step_per_gpu": B, "proof_bytes": pb, "parallelism": "independent proofs sharded by index"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "whole_path": whole_path,
-            "kernels_ms_per_chunk32": {k: round(v[0], 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1][0])},
+            "chunk_proofs": chunk if rank == 0 else None, "kernels_ms_per_chunk": {k: round(v[0], 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1][0])},
         }
         print(json.dumps(out))
     if dist:

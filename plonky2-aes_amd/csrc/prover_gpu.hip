@@ -97,7 +97,7 @@ struct p2_circuit {
     hipStream_t cur_stream() { return cur ? cur->stream : stream; }
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>>& cur_pending() { return cur ? cur->pending : setup_ws.pending; }
     u32 ws_inputs = 0;
-    size_t chunk = 0;
+    size_t chunk = 0, ws_alloc_begin = 0;  // allocs[ws_alloc_begin..] belong to the workspaces
     // timing
     bool timing_on = false;
     std::map<std::string, std::pair<float, u32>> times;
@@ -445,12 +445,35 @@ static int circuit_setup(p2_circuit* C) {
 }
 
 static int setup_polyrefs(p2_circuit* C);
+static void collect_timing(p2_circuit* C);
 static int alloc_workspace(p2_circuit* C, size_t chunk, u32 n_inputs, size_t nstreams) {
     const Circuit& c = C->c;
     const size_t n = C->n, N = C->N;
     const u32 zc = c.num_zs_cols(), qc = c.num_quotient_cols(), NC = c.cfg.num_challenges, act = C->active_wires;
     if (C->chunk >= chunk && C->ws_inputs >= n_inputs && C->ws.size() >= nstreams) return 0;
-    if (C->chunk != 0) return set_error("workspace already allocated with a smaller shape; create a new p2_circuit"), P2_ERR_INVALID;
+    const size_t old_streams = C->ws.size();
+    if (C->chunk != 0) {
+        // a later call wants a bigger shape (a first prove(pw) sizes the workspace for one proof; a batch follows):
+        // drain the proving streams, release the old workspaces and allocate the larger ones
+        if (C->timing_on) collect_timing(C);
+        for (Workspace* W : C->ws) {
+            HIPCHECK(hipStreamSynchronize(W->stream));
+            for (auto& pe : W->pending) {
+                (void)hipEventDestroy(pe.second.first);
+                (void)hipEventDestroy(pe.second.second);
+            }
+            (void)hipStreamDestroy(W->stream);
+            (void)hipEventDestroy(W->done);
+            delete W;
+        }
+        C->ws.clear();
+        for (size_t i = C->ws_alloc_begin; i < C->allocs.size(); i++) (void)hipFree(C->allocs[i]);
+        C->allocs.resize(C->ws_alloc_begin);
+        chunk = std::max(chunk, C->chunk);
+        n_inputs = std::max(n_inputs, C->ws_inputs);
+        nstreams = std::max(nstreams, old_streams);
+    }
+    C->ws_alloc_begin = C->allocs.size();
     C->chunk = chunk;
     C->ws_inputs = std::max<u32>(n_inputs, 1);
     int e = 0;
@@ -972,24 +995,29 @@ int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets,
         if (slot < 0) return set_error("input target is not a target of this circuit"), P2_ERR_INVALID;
         slots[i] = (u32)slot;
     }
-    // chunk size / stream count: P2AES_CHUNK (default 32 proofs), P2AES_STREAMS (default 2)
-    size_t want_chunk = 32, want_streams = 2;
+    // Chunk size / stream count: P2AES_CHUNK (default 128 proofs per chunk), P2AES_STREAMS (default 2).  A batch smaller
+    // than chunk x streams is split evenly over the streams, so that the serial stages of one chunk (witness levels,
+    // the Fiat-Shamir chain, proof-of-work) overlap the wide kernels of the other.  A later, larger batch regrows the
+    // workspaces (alloc_workspace); a smaller one runs in the existing ones.
+    size_t want_chunk = 128, want_streams = 2;
     if (const char* e = getenv("P2AES_CHUNK")) want_chunk = std::max(1, atoi(e));
     if (const char* e = getenv("P2AES_STREAMS")) want_streams = std::min(8, std::max(1, atoi(e)));
     {
-        // cap the chunk so that all workspaces fit in ~70% of the free HBM
+        // cap the chunk so that all workspaces fit in ~70% of the HBM that is free (plus what the workspaces hold now)
         const Circuit& c = C->c;
         size_t n = C->n, N = C->N, zc = c.num_zs_cols(), qc = c.num_quotient_cols(), act = C->active_wires, NC = c.cfg.num_challenges;
         size_t words = c.num_slots + (act + zc) * 2 * n + qc * n + (act + zc + qc) * N + NC * (c.num_partial_products() + c.num_sldc_polys() + 2) * n +
                        2 * NC * N + 3 * 8 * N + 16 * n + 4 * N;
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && !C->chunk) {
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            free_b += 8 * words * C->chunk * C->ws.size();
             size_t fit = (size_t)(0.7 * (double)free_b) / (8 * words * want_streams);
             want_chunk = std::max<size_t>(1, std::min(want_chunk, fit));
         }
     }
-    size_t chunk = C->chunk ? C->chunk : std::min<size_t>(std::max<size_t>(batch, 1), want_chunk);
-    size_t nstreams = C->chunk ? C->ws.size() : std::min(want_streams, (batch + chunk - 1) / chunk);
+    size_t nstreams = std::min(want_streams, std::max<size_t>(batch, 1));
+    size_t chunk = std::min(want_chunk, (std::max<size_t>(batch, 1) + nstreams - 1) / nstreams);
+    if (C->chunk >= chunk && C->ws.size() >= nstreams) chunk = C->chunk, nstreams = C->ws.size();
     if (alloc_workspace(C, chunk, (u32)n_targets, nstreams)) return P2_ERR_HIP;
     // Ordering with the caller: the proving streams wait for everything already enqueued on the caller's stream (its
     // inputs) and the caller's stream then waits for the proofs.  NULL means the legacy default stream, which is
@@ -1022,6 +1050,7 @@ int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets,
 }
 
 int p2_circuit_synchronize(p2_circuit* C) {
+    std::lock_guard<std::mutex> lock(C->mu);
     HIPCHECK(hipSetDevice(C->device));
     HIPCHECK(hipStreamSynchronize(C->stream));
     for (Workspace* W : C->ws) HIPCHECK(hipStreamSynchronize(W->stream));
@@ -1088,11 +1117,13 @@ int p2_prove_batch(p2_circuit* C, size_t batch, const p2_assignment* inputs, uin
 }
 
 int p2_circuit_set_timing(p2_circuit* C, int enable) {
+    std::lock_guard<std::mutex> lock(C->mu);
     C->timing_on = enable != 0;
     C->times.clear();
     return P2_OK;
 }
 size_t p2_circuit_get_timing(p2_circuit* C, p2_kernel_time* out, size_t cap) {
+    std::lock_guard<std::mutex> lock(C->mu);
     size_t k = 0;
     for (auto& kv : C->times) {
         if (k < cap) {
@@ -1107,6 +1138,7 @@ size_t p2_circuit_get_timing(p2_circuit* C, p2_kernel_time* out, size_t cap) {
 }
 
 int p2_circuit_debug_read(p2_circuit* C, const char* name_c, size_t index, uint64_t* out, size_t cap, size_t* n_written) {
+    std::lock_guard<std::mutex> lock(C->mu);
     HIPCHECK(hipSetDevice(C->device));
     HIPCHECK(hipDeviceSynchronize());
     const Circuit& c = C->c;

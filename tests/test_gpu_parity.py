@@ -309,3 +309,31 @@ def test_zero_knowledge_config_bit_exact(gpu, orc):
 def test_random_circuits_bit_exact(gpu, orc, seed):
     data, pws = circuits.random_circuit(gpu, orc, seed, n_ops=80, n_witnesses=3)
     _gpu_vs_oracle(gpu, orc, data, pws)
+
+
+def test_concurrent_prove_calls_on_one_handle(gpu, orc):
+    """`prove(&self)` takes a shared reference and CircuitData is reused across witnesses
+    (circuit_aes.rs:394-410), so one handle must serve concurrent p2_prove_batch calls.  Four host threads prove
+    different witnesses at once (ctypes drops the GIL inside the call); every proof equals the oracle's."""
+    import threading
+    r = random.Random(40)
+    keys = [(bytes(r.randrange(256) for _ in range(16)), bytes(r.randrange(256) for _ in range(12)), bytes(r.randrange(256) for _ in range(64)))
+            for _ in range(12)]
+    data, pws, _ = circuits.encrypt(gpu, 4, 64, False, keys=keys)
+    oc = orc.OracleCircuit(data.blob)
+    data.prove_batch(pws[:3])  # workspace sized for three proofs per call before the threads start
+    results = [None] * 4
+
+    def work(i):
+        results[i] = data.prove_batch(pws[3 * i:3 * i + 3])
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(4):
+        proofs, status = results[i]
+        assert status == [0, 0, 0]
+        for pw, proof in zip(pws[3 * i:3 * i + 3], proofs):
+            assert proof == oc.prove(pw.map)[1]
