@@ -296,9 +296,7 @@ struct WitnessArgs {
     const u32* input_slots;   // [n_inputs] (shared by the batch)
     const u64* input_values;  // [batch][n_inputs]
     u64* values;              // [batch][num_slots]
-    const int32_t* lut_idx;   // [num_luts][65536] input value -> table index or -1
-    const u32* lut_pairs;     // flat: (out<<16 | in) per entry
-    const u32* lut_offsets;   // [num_luts+1]
+    const u64* lut_ent;       // [num_luts][65536] input value -> (flat table entry index << 16) | output, or ~0
     u32* mult;                // [batch][total_lut_entries] multiplicity counters (zeroed by the caller)
     size_t total_lut_entries;
     int* status;              // [batch]
@@ -307,8 +305,40 @@ struct WitnessArgs {
     u32 n, num_poseidon_rows;
 };
 
+// Ops a thread keeps in flight together.  Measured on the 2^19-row AES-GCM circuit: 1, 2 and 4 give the same 15 us per
+// 3.8k-op level -- one CU sustains ~2e8 random 8-byte accesses/s whatever the issue order (outstanding-miss capacity x
+// HBM latency), so the remedy for deep circuits is more CUs per witness, not more loads per thread.
+static const int WITNESS_MLP = 1;
+// PoseidonGenerator: one thread computes the whole row (these ops form sequential sponge chains).  0 ok, 1 conflict, 2 missing input
+__device__ __noinline__ int witness_poseidon_op(const WitnessArgs& a, u64* val, u32 proof, const p2::Op& o) {
+    u64 w[135];
+    int bad = 0;
+    const u32 row = o.a;
+    for (u32 c = 0; c < 12; c++) {
+        w[c] = val[a.wire_slot[(size_t)c * a.n + row]];
+        if (w[c] == UNSET) bad = 2;
+    }
+    w[p2::PG_SWAP] = val[a.wire_slot[(size_t)p2::PG_SWAP * a.n + row]];
+    if (w[p2::PG_SWAP] == UNSET) bad = 2;
+    if (bad) return bad;
+    p2::poseidon_gate_witness(w);
+    for (u32 c = p2::PG_OUT; c < 80; c++) {
+        if (c == p2::PG_SWAP) continue;
+        u32 sl = (u32)a.wire_slot[(size_t)c * a.n + row];
+        u64 cur = val[sl];
+        if (cur == UNSET)
+            val[sl] = w[c];
+        else if (cur != w[c])
+            bad = 1;
+    }
+    u64* adv = a.advice + ((size_t)proof * a.num_poseidon_rows + o.aux) * 55;
+    for (u32 c = 80; c < 135; c++) adv[c - 80] = w[c];
+    return bad;
+}
+
 // One workgroup generates one witness: ops are pre-sorted into dependency levels; every level is a parallel
 // sweep of the workgroup with a barrier in between (the op descriptors are shared by all proofs, L2-resident).
+template <bool HAS_POSEIDON>
 __global__ __launch_bounds__(1024) void k_witness(WitnessArgs a) {
     __shared__ int s_status;
     const u32 proof = blockIdx.x;
@@ -317,19 +347,22 @@ __global__ __launch_bounds__(1024) void k_witness(WitnessArgs a) {
     if (threadIdx.x == 0) s_status = 0;
     for (u32 i = threadIdx.x; i < a.num_slots; i += blockDim.x) val[i] = UNSET;
     __syncthreads();
-    // PartialWitness::set_target: one thread walks the inputs so that duplicate targets are checked in order
-    if (threadIdx.x == 0) {
+    // PartialWitness::set_target for every input at once: a slot takes the first value that reaches it (compare-and-swap
+    // against the unset marker) and any later, different value is a conflict -- the outcome does not depend on the order
+    {
         const u64* iv = a.input_values + (size_t)proof * a.n_inputs;
-        for (u32 i = 0; i < a.n_inputs; i++) {
-            u32 s = a.input_slots[i];
-            u64 v = iv[i];
+        int bad = 0;
+        for (u32 i = threadIdx.x; i < a.n_inputs; i += blockDim.x) {
+            const u64 v = iv[i];
             if (v == UNSET) continue;  // this witness does not assign the target (batches share one target list)
-            if (v >= gl::P) s_status = 3;
-            if (val[s] == UNSET)
-                val[s] = v;
-            else if (val[s] != v)
-                s_status = 3;
+            if (v >= gl::P) {
+                bad = 1;
+                continue;
+            }
+            const u64 old = atomicCAS((unsigned long long*)&val[a.input_slots[i]], (unsigned long long)UNSET, (unsigned long long)v);
+            if (old != UNSET && old != v) bad = 1;
         }
+        if (bad) atomicMax(&s_status, 3);
     }
     __syncthreads();
     // The op descriptors do not depend on witness values, so each thread fetches its first descriptor of level lv+1
@@ -355,77 +388,76 @@ __global__ __launch_bounds__(1024) void k_witness(WitnessArgs a) {
                 have_nxt = true;
             }
         }
-        for (u32 k = beg + threadIdx.x; k < end; k += blockDim.x) {
-            const p2::Op o = (have_first && k == beg + threadIdx.x) ? first : a.ops[k];
-            u64 r = 0;
-            int bad = 0;
-            if (o.kind == p2::OP_ARITH) {
-                u64 x = val[o.a], y = val[o.b], z = val[o.c];
-                if (x == UNSET || y == UNSET || z == UNSET)
-                    bad = 2;
-                else
-                    r = gl::add(gl::mul(gl::mul(x, y), o.k0), gl::mul(z, o.k1));
-            } else if (o.kind == p2::OP_CONST) {
-                r = o.k0;
-            } else if (o.kind == p2::OP_LOOKUP) {
-                u64 x = val[o.a];
-                if (x == UNSET) {
-                    bad = 2;
-                } else if (x >= 65536) {
-                    bad = 1;
-                } else {
-                    int32_t idx = a.lut_idx[(size_t)o.aux * 65536 + x];
-                    if (idx < 0) {
+        // stages of an op: descriptor, then every operand together with the present value of the output slot (it does
+        // not depend on the operands), then the table entry of a lookup; WITNESS_MLP ops go through them side by side
+        for (u32 k0 = beg + threadIdx.x; k0 < end; k0 += WITNESS_MLP * blockDim.x) {
+            p2::Op o[WITNESS_MLP];
+            bool act[WITNESS_MLP];
+#pragma unroll
+            for (int u = 0; u < WITNESS_MLP; u++) {
+                const u32 k = k0 + u * blockDim.x;
+                act[u] = k < end;
+                if (act[u]) o[u] = (u == 0 && have_first && k0 == beg + threadIdx.x) ? first : a.ops[k];
+            }
+            u64 x[WITNESS_MLP], y[WITNESS_MLP], z[WITNESS_MLP], cur[WITNESS_MLP], ent[WITNESS_MLP];
+#pragma unroll
+            for (int u = 0; u < WITNESS_MLP; u++) {
+                x[u] = y[u] = z[u] = cur[u] = 0;
+                if (!act[u] || o[u].kind == p2::OP_POSEIDON) continue;
+                const u32 kind = o[u].kind;
+                cur[u] = val[o[u].out];
+                if (kind != p2::OP_CONST) x[u] = val[o[u].a];
+                if (kind == p2::OP_ARITH || kind == p2::OP_EQ || kind == p2::OP_EQINV) y[u] = val[o[u].b];
+                if (kind == p2::OP_ARITH) z[u] = val[o[u].c];
+            }
+#pragma unroll
+            for (int u = 0; u < WITNESS_MLP; u++) {
+                ent[u] = ~0ull;  // (flat entry index << 16) | output, or ~0
+                if (act[u] && o[u].kind == p2::OP_LOOKUP && x[u] < 65536) ent[u] = a.lut_ent[(size_t)o[u].aux * 65536 + x[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < WITNESS_MLP; u++) {
+                if (!act[u]) continue;
+                const u32 kind = o[u].kind;
+                u64 r = 0;
+                int bad = 0;
+                if (kind == p2::OP_POSEIDON) {
+                    if (HAS_POSEIDON) bad = witness_poseidon_op(a, val, proof, o[u]);
+                    if (bad) atomicMax(&s_status, bad == 1 ? 3 : 2);
+                    continue;
+                }
+                if (kind == p2::OP_ARITH) {
+                    if (x[u] == UNSET || y[u] == UNSET || z[u] == UNSET)
+                        bad = 2;
+                    else
+                        r = gl::add(gl::mul(gl::mul(x[u], y[u]), o[u].k0), gl::mul(z[u], o[u].k1));
+                } else if (kind == p2::OP_CONST) {
+                    r = o[u].k0;
+                } else if (kind == p2::OP_LOOKUP) {
+                    if (x[u] == UNSET) {
+                        bad = 2;
+                    } else if (ent[u] == ~0ull) {  // not a 16-bit value, or not in the table
                         bad = 1;
                     } else {
-                        u32 e = a.lut_offsets[o.aux] + (u32)idx;
-                        r = a.lut_pairs[e] >> 16;
-                        atomicAdd(&mult[e], 1u);
+                        r = ent[u] & 0xFFFF;
+                        atomicAdd(&mult[ent[u] >> 16], 1u);
                     }
+                } else {
+                    if (x[u] == UNSET || y[u] == UNSET)
+                        bad = 2;
+                    else if (kind == p2::OP_EQ)
+                        r = x[u] == y[u] ? 1 : 0;
+                    else
+                        r = x[u] == y[u] ? 0 : gl::inv(gl::sub(x[u], y[u]));
                 }
-            } else if (o.kind == p2::OP_POSEIDON) {
-                // PoseidonGenerator: one thread computes the whole row (these ops form sequential sponge chains)
-                u64 w[135];
-                const u32 row = o.a;
-                for (u32 c = 0; c < 12; c++) {
-                    w[c] = val[a.wire_slot[(size_t)c * a.n + row]];
-                    if (w[c] == UNSET) bad = 2;
-                }
-                w[p2::PG_SWAP] = val[a.wire_slot[(size_t)p2::PG_SWAP * a.n + row]];
-                if (w[p2::PG_SWAP] == UNSET) bad = 2;
                 if (!bad) {
-                    p2::poseidon_gate_witness(w);
-                    for (u32 c = p2::PG_OUT; c < 80; c++) {
-                        if (c == p2::PG_SWAP) continue;
-                        u32 sl = (u32)a.wire_slot[(size_t)c * a.n + row];
-                        u64 cur = val[sl];
-                        if (cur == UNSET)
-                            val[sl] = w[c];
-                        else if (cur != w[c])
-                            bad = 1;
-                    }
-                    u64* adv = a.advice + ((size_t)proof * a.num_poseidon_rows + o.aux) * 55;
-                    for (u32 c = 80; c < 135; c++) adv[c - 80] = w[c];
+                    if (cur[u] == UNSET)
+                        val[o[u].out] = r;
+                    else if (cur[u] != r)
+                        bad = 1;
                 }
-                if (bad) atomicMax(&s_status, bad == 1 ? 3 : 2);
-                continue;
-            } else {
-                u64 x = val[o.a], y = val[o.b];
-                if (x == UNSET || y == UNSET)
-                    bad = 2;
-                else if (o.kind == p2::OP_EQ)
-                    r = x == y ? 1 : 0;
-                else
-                    r = x == y ? 0 : gl::inv(gl::sub(x, y));
+                if (bad) atomicMax(&s_status, bad == 1 ? 3 : 2);  // conflict (1) outranks missing input (2); remapped below
             }
-            if (!bad) {
-                u64 cur = val[o.out];
-                if (cur == UNSET)
-                    val[o.out] = r;
-                else if (cur != r)
-                    bad = 1;
-            }
-            if (bad) atomicMax(&s_status, bad == 1 ? 3 : 2);  // conflict (1) outranks missing input (2); remapped below
         }
         __syncthreads();
     }

@@ -68,7 +68,8 @@ struct p2_circuit {
     // ---- static device data
     Op* d_ops = nullptr;
     u32* d_level_offsets = nullptr;
-    int32_t *d_wire_slot = nullptr, *d_lut_idx = nullptr;
+    int32_t* d_wire_slot = nullptr;
+    u64* d_lut_ent = nullptr;
     u32 *d_lut_pairs = nullptr, *d_lut_offsets = nullptr, *d_num_lookups = nullptr;
     LookupRows* d_lookup_rows = nullptr;
     int32_t* d_pos_index = nullptr;  // [n] advice block of a PoseidonGate row, else -1
@@ -282,18 +283,19 @@ static int circuit_setup(p2_circuit* C) {
     if (upload(C, &C->d_level_offsets, c.level_offsets.data(), c.level_offsets.size())) return P2_ERR_HIP;
     if (upload(C, &C->d_wire_slot, c.wire_slot.data(), c.wire_slot.size())) return P2_ERR_HIP;
     {
-        std::vector<int32_t> idx(c.luts.size() * 65536, -1);
+        // witness generation resolves a lookup with ONE load: input value -> (flat entry index << 16) | output
+        std::vector<u64> ent(c.luts.size() * 65536, ~0ull);
         std::vector<u32> pairs, offs(1, 0);
         for (size_t l = 0; l < c.luts.size(); l++) {
             for (size_t i = 0; i < c.luts[l].size(); i++) {
                 auto pr = c.luts[l][i];
-                if (idx[l * 65536 + pr.first] < 0) idx[l * 65536 + pr.first] = (int32_t)i;
+                if (ent[l * 65536 + pr.first] == ~0ull) ent[l * 65536 + pr.first] = ((u64)pairs.size() << 16) | pr.second;
                 pairs.push_back((u32)pr.first | ((u32)pr.second << 16));
             }
             offs.push_back((u32)pairs.size());
         }
         C->total_lut_entries = pairs.size();
-        if (upload(C, &C->d_lut_idx, idx.data(), idx.size())) return P2_ERR_HIP;
+        if (upload(C, &C->d_lut_ent, ent.data(), ent.size())) return P2_ERR_HIP;
         if (upload(C, &C->d_lut_pairs, pairs.data(), pairs.size())) return P2_ERR_HIP;
         if (upload(C, &C->d_lut_offsets, offs.data(), offs.size())) return P2_ERR_HIP;
         if (upload(C, &C->d_num_lookups, c.num_lookups.data(), c.num_lookups.size())) return P2_ERR_HIP;
@@ -554,9 +556,7 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         a.input_slots = C->cur->d_input_slots;
         a.input_values = d_values;
         a.values = C->cur->d_values;
-        a.lut_idx = C->d_lut_idx;
-        a.lut_pairs = C->d_lut_pairs;
-        a.lut_offsets = C->d_lut_offsets;
+        a.lut_ent = C->d_lut_ent;
         a.mult = C->cur->d_mult;
         a.total_lut_entries = C->total_lut_entries;
         a.status = C->cur->d_status;
@@ -564,7 +564,10 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         a.advice = C->cur->d_advice;
         a.n = (u32)n;
         a.num_poseidon_rows = (u32)c.poseidon_rows.size();
-        LAUNCH(C, "witness", k_witness, dim3(B), dim3(1024), 0, a);
+        if (c.poseidon_rows.empty())
+            LAUNCH(C, "witness", k_witness<false>, dim3(B), dim3(1024), 0, a);
+        else
+            LAUNCH(C, "witness", k_witness<true>, dim3(B), dim3(1024), 0, a);
     }
     LAUNCH(C, "fill_wires", k_fill_wires, g1((size_t)R * n, 256, B), dim3(256), 0, C->d_wire_slot, C->cur->d_values, C->cur->d_wires, (size_t)R * n, c.num_slots, ws,
            C->cur->d_status);
