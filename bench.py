@@ -143,10 +143,20 @@ def main():
     status = torch.zeros(B, dtype=torch.int32, device="cuda")
     tarr = (C.c_uint64 * nt)(*targets)
 
-    torch_stream = torch.cuda.current_stream().cuda_stream  # orders the proving streams after the tensors above
+    # A call is ordered with the stream it is given: that stream waits for the proofs, so calls issued on ONE stream drain
+    # the chip at every step boundary.  Successive steps therefore alternate between two caller streams (both ordered
+    # after the input tensors), the way a service keeps two batches in flight: step k+1's witness generation runs under
+    # step k's commitments.  Everything is complete before the clock stops (synchronize below).
+    callers = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for cs in callers:
+        cs.wait_stream(torch.cuda.current_stream())
+    torch_stream = torch.cuda.current_stream().cuda_stream
+    step_no = [0]
 
     def step():
-        rc = lib.p2_prove_batch_device(h, B, tarr, nt, vals.data_ptr(), proofs.data_ptr(), status.data_ptr(), torch_stream)
+        cs = callers[step_no[0] % 2].cuda_stream
+        step_no[0] += 1
+        rc = lib.p2_prove_batch_device(h, B, tarr, nt, vals.data_ptr(), proofs.data_ptr(), status.data_ptr(), cs)
         if rc:
             raise RuntimeError(lib.p2_last_error().decode())
 

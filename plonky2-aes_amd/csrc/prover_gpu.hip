@@ -97,6 +97,8 @@ struct p2_circuit {
     Workspace setup_ws;        // used before any per-chunk workspace exists (preprocessing, primitives)
     hipStream_t cur_stream() { return cur ? cur->stream : stream; }
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>>& cur_pending() { return cur ? cur->pending : setup_ws.pending; }
+    hipEvent_t ev_witness = nullptr;  // end of the latest witness kernel on any proving stream
+    bool witness_recorded = false;
     u32 ws_inputs = 0;
     size_t chunk = 0, ws_alloc_begin = 0;  // allocs[ws_alloc_begin..] belong to the workspaces
     // timing
@@ -564,10 +566,20 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         a.advice = C->cur->d_advice;
         a.n = (u32)n;
         a.num_poseidon_rows = (u32)c.poseidon_rows.size();
+        // 512 threads (8 waves, <= 128 VGPRs each) leave room on the compute unit: a 1024-thread workgroup needs a
+        // completely empty unit and waits for the tail of whatever wide kernel the other stream is running.
+        const u32 WITNESS_THREADS = 512;
+        // Witness kernels of successive chunks run one after the other (each occupies only B compute units): without
+        // this the two proving streams stay in lockstep -- both in witness generation with the chip idle, then both in
+        // the wide kernels -- and a deep circuit's witness time is never hidden.  Chained, chunk k+1's witness runs
+        // under chunk k's commitments.
+        if (C->witness_recorded) HIPCHECK(hipStreamWaitEvent(C->cur->stream, C->ev_witness, 0));
         if (c.poseidon_rows.empty())
-            LAUNCH(C, "witness", k_witness<false>, dim3(B), dim3(1024), 0, a);
+            LAUNCH(C, "witness", k_witness<false>, dim3(B), dim3(WITNESS_THREADS), 0, a);
         else
-            LAUNCH(C, "witness", k_witness<true>, dim3(B), dim3(1024), 0, a);
+            LAUNCH(C, "witness", k_witness<true>, dim3(B), dim3(WITNESS_THREADS), 0, a);
+        HIPCHECK(hipEventRecord(C->ev_witness, C->cur->stream));
+        C->witness_recorded = true;
     }
     LAUNCH(C, "fill_wires", k_fill_wires, g1((size_t)R * n, 256, B), dim3(256), 0, C->d_wire_slot, C->cur->d_values, C->cur->d_wires, (size_t)R * n, c.num_slots, ws,
            C->cur->d_status);
@@ -891,6 +903,7 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
         C->pbytes = proof_bytes(c);
         if (hipSetDevice(device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
         if (hipStreamCreate(&C->stream) != hipSuccess) throw std::runtime_error("hipStreamCreate failed");
+        if (hipEventCreateWithFlags(&C->ev_witness, hipEventDisableTiming) != hipSuccess) throw std::runtime_error("hipEventCreate failed");
         if (hipFuncSetAttribute((const void*)k_ntt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
             throw std::runtime_error("cannot raise the dynamic LDS limit to 128 KiB");
         if (hipFuncSetAttribute((const void*)k_ntt_pass1, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
@@ -946,6 +959,7 @@ void p2_circuit_free(p2_circuit* C) {
         delete W;
     }
     if (C->stream) (void)hipStreamDestroy(C->stream);
+    if (C->ev_witness) (void)hipEventDestroy(C->ev_witness);
     delete C;
 }
 
