@@ -302,51 +302,60 @@ __global__ __launch_bounds__(256) void k_fri_compose(const PolyRef* __restrict__
 __global__ __launch_bounds__(1024) void k_fri_divide(const u64* comp, size_t comp_batch_stride, const u64* pows, size_t pows_batch_stride, const u64* chal,
                                                       u32 n, u32 n1, u64* final_poly /*[2][n]*/, size_t final_batch_stride) {
     __shared__ u64 la[1024], lb[1024];
+    __shared__ u64 s_carry[2];
     const u32 t = threadIdx.x;
     const u64* cw = chal + (size_t)blockIdx.x * CH_WORDS;
     const E2 alpha = gl::e2(cw[CH_FRI_ALPHA], cw[CH_FRI_ALPHA + 1]);
     const E2 shift = gl::pow(alpha, n1);
     u64* fo = final_poly + (size_t)blockIdx.x * final_batch_stride;
-    const u32 per = (n + blockDim.x - 1) / blockDim.x;
-    // descending order: position d = n-1-i
-    const u32 d0 = min(n, t * per), d1 = min(n, d0 + per);
+    // Synthetic division by (X - z) is a suffix sum: Q[i] = z^-(i+1) * sum_{i' > i} comp[i'] z^i'.  The coefficients are
+    // swept from the top 1024 at a time (thread t takes i = n-1-(base+t): coalesced), a workgroup scan per sweep, the
+    // running sum carried across sweeps.
     for (u32 b = 0; b < 2; b++) {
         const u64* c = comp + (size_t)blockIdx.x * comp_batch_stride + (size_t)(2 * b) * n;
         const u64* zp = pows + (size_t)blockIdx.x * pows_batch_stride + (size_t)b * 2 * n;         // z^i
         const u64* zi = pows + (size_t)blockIdx.x * pows_batch_stride + (size_t)(2 + b) * 2 * n;   // z^-i
-        E2 seg = gl::e2(0, 0);
-        for (u32 d = d0; d < d1; d++) {
-            u32 i = n - 1 - d;
-            seg = gl::add(seg, gl::mul(gl::e2(c[i], c[n + i]), gl::e2(zp[i], zp[n + i])));
-        }
+        if (t == 0) s_carry[0] = s_carry[1] = 0;
         __syncthreads();
-        la[t] = seg.a;
-        lb[t] = seg.b;
-        __syncthreads();
-        for (u32 off = 1; off < blockDim.x; off <<= 1) {
-            u64 xa = la[t], xb = lb[t];
-            u64 ya = t >= off ? la[t - off] : 0, yb = t >= off ? lb[t - off] : 0;
+        for (u32 base = 0; base < n; base += blockDim.x) {
+            const u32 d = base + t;
+            const bool live = d < n;
+            const u32 i = live ? n - 1 - d : 0;
+            E2 term = gl::e2(0, 0);
+            if (live) term = gl::mul(gl::e2(c[i], c[n + i]), gl::e2(zp[i], zp[n + i]));
+            const E2 carry = gl::e2(s_carry[0], s_carry[1]);
+            la[t] = term.a;
+            lb[t] = term.b;
             __syncthreads();
-            la[t] = gl::add(xa, ya);
-            lb[t] = gl::add(xb, yb);
-            __syncthreads();
-        }
-        E2 acc = t == 0 ? gl::e2(0, 0) : gl::e2(la[t - 1], lb[t - 1]);
-        for (u32 d = d0; d < d1; d++) {
-            u32 i = n - 1 - d;  // acc = sum_{i' > i} comp[i'] z^i'  ->  Q[i] = acc * z^-(i+1)
-            E2 q = gl::e2(0, 0);
-            if (i + 1 < n) q = gl::mul(acc, gl::e2(zi[i + 1], zi[n + i + 1]));
-            if (b == 0) {
-                E2 s = gl::mul(q, shift);
-                fo[i] = s.a;
-                fo[n + i] = s.b;
-            } else {
-                fo[i] = gl::add(fo[i], q.a);
-                fo[n + i] = gl::add(fo[n + i], q.b);
+            for (u32 off = 1; off < blockDim.x; off <<= 1) {
+                u64 xa = la[t], xb = lb[t];
+                u64 ya = t >= off ? la[t - off] : 0, yb = t >= off ? lb[t - off] : 0;
+                __syncthreads();
+                la[t] = gl::add(xa, ya);
+                lb[t] = gl::add(xb, yb);
+                __syncthreads();
             }
-            acc = gl::add(acc, gl::mul(gl::e2(c[i], c[n + i]), gl::e2(zp[i], zp[n + i])));
+            if (live) {
+                E2 acc = gl::add(carry, t == 0 ? gl::e2(0, 0) : gl::e2(la[t - 1], lb[t - 1]));  // sum over i' > i
+                E2 q = gl::e2(0, 0);
+                if (i + 1 < n) q = gl::mul(acc, gl::e2(zi[i + 1], zi[n + i + 1]));
+                if (b == 0) {
+                    E2 s = gl::mul(q, shift);
+                    fo[i] = s.a;
+                    fo[n + i] = s.b;
+                } else {
+                    fo[i] = gl::add(fo[i], q.a);
+                    fo[n + i] = gl::add(fo[n + i], q.b);
+                }
+            }
+            __syncthreads();
+            if (t == blockDim.x - 1) {
+                E2 tot = gl::add(carry, gl::e2(la[t], lb[t]));
+                s_carry[0] = tot.a;
+                s_carry[1] = tot.b;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 // fold coefficients by beta: out[k] = sum_{i<arity} beta^i in[arity*k + i];  in/out: [2][len] component columns

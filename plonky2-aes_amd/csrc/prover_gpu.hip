@@ -281,6 +281,7 @@ static int circuit_setup(p2_circuit* C) {
     const Circuit& c = C->c;
     const size_t n = C->n, N = C->N;
     const u32 R = c.cfg.num_routed_wires, ncc = c.num_constants_cols(), np = c.num_preprocessed();
+    if (c.num_partial_products() + 1 > PERM_MAX_CHUNKS) return set_error("more partial-product chunks than k_perm_scan holds in registers"), P2_ERR_INVALID;
     if (upload(C, &C->d_ops, c.ops.data(), c.ops.size())) return P2_ERR_HIP;
     if (upload(C, &C->d_level_offsets, c.level_offsets.data(), c.level_offsets.size())) return P2_ERR_HIP;
     if (upload(C, &C->d_wire_slot, c.wire_slot.data(), c.wire_slot.size())) return P2_ERR_HIP;
