@@ -8,11 +8,10 @@ pkg = g.load_package()
 import circuits, random
 r = random.Random(1)
 L = 1024
-keys = [(bytes(r.randrange(256) for _ in range(16)), bytes(r.randrange(256) for _ in range(12)), bytes(r.randrange(256) for _ in range(L))) for _ in range(64)]
+keys = [(bytes(r.randrange(256) for _ in range(16)), bytes(r.randrange(256) for _ in range(12)), bytes(r.randrange(256) for _ in range(L))) for _ in range(256)]
 data, pws, _ = circuits.encrypt(pkg, 4, L, False, keys=keys)
 data.gpu()
-for B in (1, 1, 2, 4, 8, 16, 32, 64):
-    os.environ["P2AES_CHUNK"] = str(max(1, min(32, B)))
+for B in (1, 1, 2, 4, 8, 16, 32, 64, 256):
     d2 = pkg.CircuitData(data.blob); d2.gpu()
     d2.prove_batch(pws[:B])  # warm-up (allocates the workspace)
     t0 = time.perf_counter(); n = 3
