@@ -403,8 +403,8 @@ class CircuitData:
         status = (C.c_int * B)()
         if lib().p2_prove_batch(self.gpu(), B, asg, buf, status):
             raise P2Error("p2_prove_batch failed: " + _err())
-        pb = self.proof_bytes
-        return [buf.raw[i * pb:(i + 1) * pb] if status[i] == 0 else None for i in range(B)], list(status)
+        pb, base = self.proof_bytes, C.addressof(buf)   # (buf.raw would copy the whole buffer once per proof)
+        return [C.string_at(base + i * pb, pb) if status[i] == 0 else None for i in range(B)], list(status)
 
     def prove_batch_device(self, targets, d_values, d_proofs, d_status, batch, stream=None):
         """Device-resident path: `d_values` [batch][len(targets)] u64, `d_proofs` batch*proof_bytes bytes and `d_status`

@@ -2,6 +2,7 @@
 // Replaces `CircuitData::prove(pw)` (reference call sites: SURVEY.md A.2) with a sequence of HIP kernels on one
 // stream per circuit handle; no host synchronisation between stages (Fiat-Shamir runs in a device kernel).
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <map>
@@ -1111,17 +1112,25 @@ int p2_prove_batch(p2_circuit* C, size_t batch, const p2_assignment* inputs, uin
     u64* d_vals = nullptr;
     uint8_t* d_proofs = nullptr;
     int* d_stat = nullptr;
+    const bool dbg = getenv("P2AES_DEBUG_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_a = now();
     HIPCHECK(hipMalloc((void**)&d_vals, hv.size() * 8));
     HIPCHECK(hipMalloc((void**)&d_proofs, batch * C->pbytes));
     HIPCHECK(hipMalloc((void**)&d_stat, batch * sizeof(int)));
     HIPCHECK(hipMemcpy(d_vals, hv.data(), hv.size() * 8, hipMemcpyHostToDevice));
+    double t_b = now();
     int rc = p2_prove_batch_device(C, batch, targets, nt, d_vals, d_proofs, d_stat, nullptr);
+    double t_c = now();
     if (rc == P2_OK) rc = p2_circuit_synchronize(C);
+    double t_d = now();
+    if (dbg) fprintf(stderr, "[p2aes] alloc+h2d %.3f enqueue %.3f wait %.3f s\n", t_b - t_a, t_c - t_b, t_d - t_c);
     if (rc == P2_OK) {
         if (hipMemcpy(proofs, d_proofs, batch * C->pbytes, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(status, d_stat, batch * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
             set_error("copying proofs back failed");
             rc = P2_ERR_HIP;
         }
+        if (dbg) fprintf(stderr, "[p2aes] copy back %.3f s\n", now() - t_d);
         for (size_t i = 0; i < batch && rc == P2_OK; i++)
             if (host_status[i]) {
                 status[i] = host_status[i];
