@@ -337,3 +337,29 @@ def test_concurrent_prove_calls_on_one_handle(gpu, orc):
         assert status == [0, 0, 0]
         for pw, proof in zip(pws[3 * i:3 * i + 3], proofs):
             assert proof == oc.prove(pw.map)[1]
+
+
+def test_one_handle_growing_batches_and_changing_target_lists(gpu, orc):
+    """CircuitData is built once and reused (circuit_aes.rs:394-410): a first prove(pw) sizes the workspaces for one
+    proof, later calls bring larger batches (the workspaces regrow) and different target lists (outputs assigned or
+    left to the prover) -- every proof must still equal the oracle's."""
+    r = random.Random(77)
+    keys = [(bytes(r.randrange(256) for _ in range(16)), bytes(r.randrange(256) for _ in range(12)), bytes(r.randrange(256) for _ in range(32)))
+            for _ in range(9)]
+    data, pws, t = circuits.encrypt(gpu, 4, 32, True, keys=keys)
+    oc = orc.OracleCircuit(data.blob)
+    ref = [oc.prove(pw.map)[1] for pw in pws]
+    inputs_only = []
+    for key, nonce, pt in keys:  # key, nonce, plaintext only: ciphertext and tag are computed, not checked
+        pw = gpu.PartialWitness()
+        for tt, v in zip(t.key, key):
+            pw.set_byte_target(tt, v)
+        for tt, v in zip(t.nonce, nonce):
+            pw.set_byte_target(tt, v)
+        for tt, v in zip(t.pt, pt):
+            pw.set_byte_target(tt, v)
+        inputs_only.append(pw)
+    for lo, hi, which in ((0, 1, pws), (0, 5, pws), (5, 7, inputs_only), (0, 9, pws), (2, 3, inputs_only), (0, 9, inputs_only)):
+        proofs, status = data.prove_batch(which[lo:hi])
+        assert status == [0] * (hi - lo)
+        assert proofs == ref[lo:hi]  # the same witness either way, hence the same proof
