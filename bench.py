@@ -105,12 +105,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the prover has no CPU fallback")
+    # Rehearsal on a one-GPU box (the 8-GPU run is the driver's): P2AES_BENCH_REHEARSAL=1 puts every rank on device 0 and
+    # uses gloo for the barrier / max-over-ranks, since RCCL refuses two ranks on one device.  Never set by the driver.
+    rehearsal = os.environ.get("P2AES_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     L, B = args.plaintext_bytes, args.batch
     if L > 4096 and args.batch == 256:
@@ -181,7 +189,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert int(status.abs().sum().item()) == 0
