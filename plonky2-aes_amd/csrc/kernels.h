@@ -731,24 +731,60 @@ __device__ __forceinline__ u64 block_scan_inclusive(u64 v, u64* lds) {
 
 // ------------------------------------------------------------------------------------------- permutation argument
 // q[ch][chunk][row] = prod_{j in chunk}(w_j + beta*k_j*x + gamma) / prod_{j in chunk}(w_j + beta*sigma_j + gamma)
-__global__ void k_perm_chunks(const u64* __restrict__ wires, size_t wires_batch_stride, const u64* __restrict__ sigmas, const u64* __restrict__ k_is,
-                              const u64* __restrict__ subgroup, const u64* __restrict__ chal, u64* __restrict__ q, size_t q_batch_stride, u32 n,
-                              u32 num_routed, u32 chunk_size, u32 num_chunks) {
-    u32 row = blockIdx.x * blockDim.x + threadIdx.x;
+// Thread = row.  Both challenges share every wire and sigma load, and the 2 x 10 denominators of a row are inverted
+// together (Montgomery's trick: one Fermat inversion and 3 multiplications per value instead of 20 inversions -- the
+// inversions were 3/4 of this kernel's multiplies).
+static const u32 PERM_MAX_CHUNKS = 12;
+__global__ __launch_bounds__(256) void k_perm_chunks(const u64* __restrict__ wires, size_t wires_batch_stride, const u64* __restrict__ sigmas,
+                                                     const u64* __restrict__ k_is, const u64* __restrict__ subgroup, const u64* __restrict__ chal,
+                                                     u64* __restrict__ q, size_t q_batch_stride, u32 n, u32 num_routed, u32 chunk_size, u32 num_chunks,
+                                                     u32 num_challenges) {
+    const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
-    u32 chunk = blockIdx.z % num_chunks, ch = blockIdx.z / num_chunks;
     const u64* cw = chal + (size_t)blockIdx.y * CH_WORDS;
-    u64 beta = cw[CH_BETAS + ch], gamma = cw[CH_GAMMAS + ch];
-    const u64* w = wires + (size_t)blockIdx.y * wires_batch_stride;
-    u64 bx = gl::mul(beta, subgroup[row]);
-    u64 num = 1, den = 1;
-    u32 j1 = min(num_routed, (chunk + 1) * chunk_size);
-    for (u32 j = chunk * chunk_size; j < j1; j++) {
-        u64 wv = w[(size_t)j * n + row];
-        num = gl::mul(num, gl::add(gl::add(wv, gl::mul(bx, k_is[j])), gamma));
-        den = gl::mul(den, gl::add(gl::add(wv, gl::mul(beta, sigmas[(size_t)j * n + row])), gamma));
+    const u64* w = wires + (size_t)blockIdx.y * wires_batch_stride + row;
+    const u64* sg = sigmas + row;
+    const bool two = num_challenges > 1;
+    const u64 b0 = cw[CH_BETAS], g0 = cw[CH_GAMMAS], b1 = two ? cw[CH_BETAS + 1] : 0, g1 = two ? cw[CH_GAMMAS + 1] : 0;
+    const u64 x = subgroup[row], bx0 = gl::mul(b0, x), bx1 = gl::mul(b1, x);
+    u64 num[2 * PERM_MAX_CHUNKS], den[2 * PERM_MAX_CHUNKS], pre[2 * PERM_MAX_CHUNKS];
+#pragma unroll
+    for (u32 c = 0; c < PERM_MAX_CHUNKS; c++) {
+        u64 n0 = 1, d0 = 1, n1 = 1, d1 = 1;
+        if (c < num_chunks) {
+            const u32 j1 = min(num_routed, (c + 1) * chunk_size);
+            for (u32 j = c * chunk_size; j < j1; j++) {
+                const u64 wv = w[(size_t)j * n], s = sg[(size_t)j * n], kj = k_is[j];
+                n0 = gl::mul(n0, gl::add(gl::add(wv, gl::mul(bx0, kj)), g0));
+                d0 = gl::mul(d0, gl::add(gl::add(wv, gl::mul(b0, s)), g0));
+                if (two) {
+                    n1 = gl::mul(n1, gl::add(gl::add(wv, gl::mul(bx1, kj)), g1));
+                    d1 = gl::mul(d1, gl::add(gl::add(wv, gl::mul(b1, s)), g1));
+                }
+            }
+        }
+        num[c] = n0;
+        den[c] = d0;
+        num[PERM_MAX_CHUNKS + c] = n1;
+        den[PERM_MAX_CHUNKS + c] = d1;
     }
-    q[(size_t)blockIdx.y * q_batch_stride + ((size_t)ch * num_chunks + chunk) * n + row] = gl::mul(num, gl::inv(den));
+    u64 run = 1;
+#pragma unroll
+    for (u32 k = 0; k < 2 * PERM_MAX_CHUNKS; k++) {
+        pre[k] = run;
+        run = gl::mul(run, den[k]);
+    }
+    // A zero denominator (probability ~2^-45 per proof; upstream's quotient computation fails on it) zeroes the whole
+    // row here, where value-by-value inversion would zero one chunk: no valid proof exists either way.
+    u64 inv = gl::inv(run);
+#pragma unroll
+    for (u32 kk = 2 * PERM_MAX_CHUNKS; kk-- > 0;) {
+        const u64 dinv = gl::mul(inv, pre[kk]);
+        inv = gl::mul(inv, den[kk]);
+        const u32 ch = kk / PERM_MAX_CHUNKS, c = kk % PERM_MAX_CHUNKS;
+        if (c < num_chunks && ch < num_challenges)
+            q[(size_t)blockIdx.y * q_batch_stride + ((size_t)ch * num_chunks + c) * n + row] = gl::mul(num[kk], dinv);
+    }
 }
 
 // Z and partial products from the chunk quotients.  One workgroup per (proof, challenge); rows are split into
@@ -758,7 +794,6 @@ __global__ void k_perm_chunks(const u64* __restrict__ wires, size_t wires_batch_
 // time -- thread t takes row base + t, so every column read and write is coalesced -- with a workgroup scan per sweep
 // and the running total carried from sweep to sweep.  (A thread-owns-16-consecutive-rows split reads each 128-byte
 // line for 8 bytes: the PMC counters showed 32x the algorithmic traffic.)
-static const u32 PERM_MAX_CHUNKS = 12;
 __global__ __launch_bounds__(1024) void k_perm_scan(const u64* __restrict__ q, size_t q_batch_stride, u64* __restrict__ zs, size_t zs_batch_stride, u32 n,
                                                      u32 num_chunks, u32 num_challenges) {
     __shared__ u64 lds[1024];

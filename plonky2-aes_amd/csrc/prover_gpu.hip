@@ -282,6 +282,7 @@ static int circuit_setup(p2_circuit* C) {
     const Circuit& c = C->c;
     const size_t n = C->n, N = C->N;
     const u32 R = c.cfg.num_routed_wires, ncc = c.num_constants_cols(), np = c.num_preprocessed();
+    if (c.cfg.num_challenges > 2) return set_error("k_perm_chunks handles at most two challenges"), P2_ERR_INVALID;
     if (c.num_partial_products() + 1 > PERM_MAX_CHUNKS) return set_error("more partial-product chunks than k_perm_scan holds in registers"), P2_ERR_INVALID;
     if (upload(C, &C->d_ops, c.ops.data(), c.ops.size())) return P2_ERR_HIP;
     if (upload(C, &C->d_level_offsets, c.level_offsets.data(), c.level_offsets.size())) return P2_ERR_HIP;
@@ -616,8 +617,8 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
     if (challenger(C, 0, C->cur->wtree.dig + cap_off(C->cur->wtree, cap_h), C->cur->wtree.stride(), cap_words, nlp ? 1 : 0, 0, B)) return P2_ERR_HIP;
     // 4. partial products and Z
     HIPCHECK(hipMemsetAsync(C->cur->d_zs, 0, (size_t)B * zs_s * 8, st));
-    LAUNCH(C, "perm_chunks", k_perm_chunks, g1(n, 256, B, NC * (npp + 1)), dim3(256), 0, C->cur->d_wires, ws, C->d_sigmas, C->d_k_is, C->d_subgroup, C->cur->d_chal,
-           C->cur->d_permq, (size_t)NC * (npp + 1) * n, (u32)n, R, c.cfg.quotient_degree_factor, npp + 1);
+    LAUNCH(C, "perm_chunks", k_perm_chunks, g1(n, 256, B), dim3(256), 0, C->cur->d_wires, ws, C->d_sigmas, C->d_k_is, C->d_subgroup, C->cur->d_chal,
+           C->cur->d_permq, (size_t)NC * (npp + 1) * n, (u32)n, R, c.cfg.quotient_degree_factor, npp + 1, NC);
     LAUNCH(C, "perm_scan", k_perm_scan, dim3(NC, B), dim3(1024), 0, C->cur->d_permq, (size_t)NC * (npp + 1) * n, C->cur->d_zs, zs_s, (u32)n, npp + 1, NC);
     // 5. lookup polynomials
     if (nlp) {
