@@ -564,30 +564,41 @@ inline Circuit CircuitBuilder::build() {
                 }
             }
         }
-        std::vector<u32> queue;
+        // The inverse hints (OP_EQINV: a 96-multiplication Fermat inversion on one lane) feed only equality checks,
+        // never the values a circuit computes with.  Left at their natural level they put an inversion into every
+        // level of a sequential chain (inc32's carry chain: four per AES-CTR block); instead they are held back until
+        // everything else is scheduled and then run side by side in one level, their checks in the levels after.
+        std::vector<u32> queue, deferred;
+        auto ready = [&](u32 i) { (ops[i].kind == OP_EQINV ? deferred : queue).push_back(i); };
         for (size_t i = 0; i < M; i++)
-            if (pending[i] == 0) queue.push_back((u32)i);
+            if (pending[i] == 0) ready((u32)i);
         size_t done = 0;
-        u32 max_level = 0;
-        while (done < queue.size()) {
-            u32 i = queue[done++];
-            u32 in[16], outs[80];
-            int k = inputs(ops[i], in);
-            int ko = outputs(ops[i], outs);
-            u32 lv = 0;
-            for (int j = 0; j < k; j++) lv = std::max(lv, slot_level[in[j]]);
-            for (int j = 0; j < ko; j++) lv = std::max(lv, slot_level[outs[j]]);
-            level[i] = lv;  // ops with only user-set inputs are level 0
-            max_level = std::max(max_level, lv);
-            for (int j = 0; j < ko; j++) {
-                u32 s = outs[j];
-                slot_level[s] = lv + 1;
-                if (!slot_ready[s]) {
-                    slot_ready[s] = 1;
-                    for (u32 cns : consumers[s])
-                        if (--pending[cns] == 0) queue.push_back(cns);
+        u32 max_level = 0, floor_level = 0;
+        for (;;) {
+            while (done < queue.size()) {
+                u32 i = queue[done++];
+                u32 in[16], outs[80];
+                int k = inputs(ops[i], in);
+                int ko = outputs(ops[i], outs);
+                u32 lv = ops[i].kind == OP_EQINV ? floor_level : 0;
+                for (int j = 0; j < k; j++) lv = std::max(lv, slot_level[in[j]]);
+                for (int j = 0; j < ko; j++) lv = std::max(lv, slot_level[outs[j]]);
+                level[i] = lv;  // ops with only user-set inputs are level 0
+                max_level = std::max(max_level, lv);
+                for (int j = 0; j < ko; j++) {
+                    u32 s = outs[j];
+                    slot_level[s] = lv + 1;
+                    if (!slot_ready[s]) {
+                        slot_ready[s] = 1;
+                        for (u32 cns : consumers[s])
+                            if (--pending[cns] == 0) ready(cns);
+                    }
                 }
             }
+            if (deferred.empty()) break;
+            floor_level = max_level + 1;
+            queue.insert(queue.end(), deferred.begin(), deferred.end());
+            deferred.clear();
         }
         if (done != M) throw std::runtime_error("witness program has a dependency cycle");
         c.level_offsets.assign(max_level + 2, 0);

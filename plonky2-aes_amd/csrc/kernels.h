@@ -305,9 +305,10 @@ struct WitnessArgs {
     u32 n, num_poseidon_rows;
 };
 
-// Ops a thread keeps in flight together.  Measured on the 2^19-row AES-GCM circuit: 1, 2 and 4 give the same 15 us per
-// 3.8k-op level -- one CU sustains ~2e8 random 8-byte accesses/s whatever the issue order (outstanding-miss capacity x
-// HBM latency), so the remedy for deep circuits is more CUs per witness, not more loads per thread.
+// Ops a thread keeps in flight together.  On the 2^19-row AES-CTR circuit 1, 2 and 4 measure the same: its 16.5 k levels
+// are the carry chain of inc32 (a handful of ops each), so a level costs its dependent memory round trips, about 4 us,
+// whatever the width.  (It cost 15 us while every level also held a Fermat inversion -- see the levelisation in
+// builder.h, which now runs the inverse hints side by side at the end.)
 static const int WITNESS_MLP = 1;
 // PoseidonGenerator: one thread computes the whole row (these ops form sequential sponge chains).  0 ok, 1 conflict, 2 missing input
 __device__ __noinline__ int witness_poseidon_op(const WitnessArgs& a, u64* val, u32 proof, const p2::Op& o) {
