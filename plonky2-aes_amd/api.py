@@ -314,7 +314,8 @@ class CircuitBuilder:
         blob, n = u8p(), sz()
         if lib().p2_builder_build(self._h, C.byref(blob), C.byref(n)):
             raise P2Error(_err())
-        data = C.string_at(blob, n.value)
+        # (ctypes.string_at takes a C int: blobs of 2^21-row circuits are larger than 2 GiB)
+        data = bytes((C.c_char * n.value).from_address(C.cast(blob, C.c_void_p).value))
         lib().p2_blob_free(blob)
         return CircuitData(data)
 

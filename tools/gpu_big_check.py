@@ -17,10 +17,11 @@ import circuits  # noqa: E402
 
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+TAG = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
 r = random.Random(1)
 keys = [(bytes(r.randrange(256) for _ in range(16)), bytes(r.randrange(256) for _ in range(12)), bytes(r.randrange(256) for _ in range(L))) for _ in range(B)]
 t0 = time.time()
-data, pws, _ = circuits.encrypt(pkg, 4, L, False, keys=keys)
+data, pws, _ = circuits.encrypt(pkg, 4, L, TAG, keys=keys)
 print("built: n=2^%d ops=%d levels=%d blob=%dMB in %.1fs" % (data.info["degree_bits"], data.info["num_ops"], data.info["num_levels"], len(data.blob) >> 20, time.time() - t0), flush=True)
 t0 = time.time()
 data.gpu()
