@@ -274,6 +274,27 @@ def test_64kib_deep_circuit_2_19_rows(gpu):
     assert status2 == [0, 1] and proofs2[0] == proofs[0]
 
 
+def test_ghash_chain_2_20_rows(gpu):
+    """AES-GCM-128 over 16 KiB WITH the tag: n = 2^20 rows, 18 M witness ops in 397 k dependency levels (the GHASH
+    chain), a 1.8 GB circuit blob; one size step beyond BASELINE's largest configuration (tools/gpu_big_check.py goes
+    to 2^22).  Same size-independent checks as above."""
+    r = random.Random(6)
+    L = 16384
+    keys = [(bytes(r.randrange(256) for _ in range(16)), bytes(r.randrange(256) for _ in range(12)), bytes(r.randrange(256) for _ in range(L)))
+            for _ in range(2)]
+    data, pws, _ = circuits.encrypt(gpu, 4, L, True, keys=keys)
+    assert data.info["degree_bits"] == 20
+    proofs, status = data.prove_batch(pws)
+    assert status == [0, 0] and proofs[0] != proofs[1]
+    data.verify(proofs[1])
+    bad = gpu.PartialWitness()
+    bad.map = dict(pws[1].map)
+    k = list(bad.map)[-1]  # last byte of the tag
+    bad.map[k] ^= 1
+    proofs2, status2 = data.prove_batch([pws[0], bad])
+    assert status2 == [0, 1] and proofs2[0] == proofs[0]
+
+
 def test_c_example_over_the_abi(gpu, tmp_path):
     """examples/aes_gcm_128.c: the reference's example program (aes-gcm/examples/aes_gcm_128.rs) from plain C."""
     import subprocess
