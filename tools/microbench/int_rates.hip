@@ -32,6 +32,18 @@ __global__ __launch_bounds__(256) void k(uint64_t* out, uint32_t seed) {
         } else if (OP == 7) {  // v_mad_u32_u16? use v_mad_u16? -> v_mul_u32_u24
 #define MU(x) { uint32_t r; asm volatile("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"((uint32_t)x), "v"(m)); x = r; }
             MU(a0); MU(a1); MU(a2); MU(a3); MU(a4); MU(a5); MU(a6); MU(a7);
+        } else if (OP == 8) {  // v_dot4_u32_u8 (4 x (8x8) + 32 -> 32)
+#define D4(x) { uint32_t r; asm volatile("v_dot4_u32_u8 %0, %1, %2, %1" : "=v"(r) : "v"((uint32_t)x), "v"(m)); x = r; }
+            D4(a0); D4(a1); D4(a2); D4(a3); D4(a4); D4(a5); D4(a6); D4(a7);
+        } else if (OP == 9) {  // v_perm_b32
+#define PB(x) { uint32_t r; asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"((uint32_t)x), "v"(m), "v"(0x07020504u)); x = r; }
+            PB(a0); PB(a1); PB(a2); PB(a3); PB(a4); PB(a5); PB(a6); PB(a7);
+        } else if (OP == 10) {  // v_cmp_lt_u64 + v_cndmask x2 (the compiler's conditional 64-bit fix-up)
+#define CF(x, y) x = (x < y) ? x + 0xFFFFFFFFull : x
+            CF(a0, a1); CF(a1, a2); CF(a2, a3); CF(a3, a4); CF(a4, a5); CF(a5, a6); CF(a6, a7); CF(a7, a0);
+        } else if (OP == 11) {  // v_dot2_u32_u16? not on gfx950 -> v_mad_u16 ; use v_pk_mad_u16
+#define PK(x) { uint32_t r; asm volatile("v_pk_mad_u16 %0, %1, %2, %1" : "=v"(r) : "v"((uint32_t)x), "v"(m)); x = r; }
+            PK(a0); PK(a1); PK(a2); PK(a3); PK(a4); PK(a5); PK(a6); PK(a7);
         }
     }
     out[t] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
@@ -62,5 +74,9 @@ int main() {
     run<7>("v_mul_u32_u24", d, 8);
     run<5>("v_lshl_add_u64", d, 7);
     run<6>("add64(compiler)", d, 8);
+    run<8>("v_dot4_u32_u8", d, 8);
+    run<9>("v_perm_b32", d, 8);
+    run<10>("cmp64+add+sel", d, 8);
+    run<11>("v_pk_mad_u16", d, 8);
     return 0;
 }
