@@ -3,7 +3,7 @@
 //     product is reduced once from 128 bits without the final conditional subtraction; outputs are canonicalised;
 //   * the 22 partial rounds use the sparse-matrix form derived by tools/gen_poseidon_fast.py: 23 multiply-accumulates
 //     per round instead of a 144-term MDS, with the 12-term dot product accumulated in 192 bits and reduced once.
-// Measured on MI355X (tools/microbench/int_rates.hip): v_mad_u64_u32 issues at ~2.3x the cost of a simple VALU op,
+// Measured on MI355X (tools/microbench/int_rates.hip): v_mad_u64_u32 issues at ~1.8x the cost of a simple VALU op,
 // so the win comes from removing instructions, not from swapping multiply flavours.
 #pragma once
 #include "gl.h"
