@@ -34,15 +34,27 @@ GL_HD void mul128(u64 a, u64 b, u64& hi, u64& lo) {
     hi = (u64)(m >> 64);
 #endif
 }
-// hi*2^64 + lo  ->  some u64 congruent mod p (plonky2 reduce128, no canonicalisation)
+// hi*2^64 + lo  ->  some u64 congruent mod p (2^64 = 2^32 - 1, 2^96 = -1; no canonicalisation).
+// T = lo + (hl << 32) - (hl + hh) is formed with 32-bit add/subtract-with-carry chains; the number of 2^64 wraps,
+// net = carry - borrow in {-1, 0, 1}, is folded back as T - net * p = T - (net << 32) ... + net, again on the halves, so no
+// 64-bit compare-and-select is needed: the compiler's version of plonky2's reduce128 spends two of those per reduction
+// (v_cmp_lt_u64 + 64-bit add + two v_cndmask + hazard padding, 5.5 issue slots each -- tools/microbench/int_rates.hip).
+// The result T - net * p lies in [0, 2^64) for every input (checked against 128-bit arithmetic on 2*10^8 inputs and all
+// combinations of extreme halves).
 GL_HD u64 red128(u64 hi, u64 lo) {
-    u64 hh = hi >> 32, hl = hi & gl::EPS;
-    u64 t0 = lo - hh;
-    if (lo < hh) t0 -= gl::EPS;
-    u64 t1 = (hl << 32) - hl;
-    u64 r = t0 + t1;
-    if (r < t1) r += gl::EPS;
-    return r;
+    const u32 l0 = (u32)lo, l1 = (u32)(lo >> 32), hl = (u32)hi, hh = (u32)(hi >> 32);
+    u32 C, cv, b, B;
+    const u32 u1 = __builtin_addc(l1, hl, 0u, &C);   // lo + (hl << 32): carry C
+    const u32 mC = 0u - C;
+    const u32 v0 = __builtin_addc(hl, hh, 0u, &cv);  // v = hl + hh, 33 bits
+    const u32 w0 = __builtin_subc(l0, v0, 0u, &b);
+    u32 w1 = __builtin_subc(u1, cv, b, &B);          // w = u - v: borrow B
+    const u32 net = 0u - mC - B;                     // C - B
+    w1 += net;                                       // + net * 2^32
+    const u32 sx = (u32)((int)net >> 31);
+    const u32 r0 = __builtin_subc(w0, net, 0u, &b);  // - net (sign-extended)
+    const u32 r1 = __builtin_subc(w1, sx, b, &B);
+    return ((u64)r1 << 32) | r0;
 }
 GL_HD u64 mulr(u64 a, u64 b) {
     u64 hi, lo;
