@@ -109,23 +109,22 @@ struct Acc {
         p = (u64)a1 * b0; t = o01 + p; co += t < p; o01 = t;
 #endif
     }
-    // value = e01 + 2^32*o01 + 2^64*(e23 + ce0 + 2^32*co) + 2^128*ce2 ; 2^128 = -2^32 (mod p); result canonical
+    // value = e01 + 2^32*o01 + 2^64*(e23 + ce0 + 2^32*co) + 2^128*ce2, summed limb by limb with carry chains (no 64-bit
+    // compares), then 2^128 = -2^32 (mod p).  Some u64 congruent to the value; not canonical.
     GL_HD u64 reduce() const {
-        // l = e01 + (o01 << 32)  as (l0, l1), l1 < 2^33
-        u64 olo = o01 << 32, ohi = o01 >> 32;
-        u64 l0 = e01 + olo;
-        u64 l1 = ohi + (l0 < olo);
-        // h = e23 + ce0 + (co << 32)  as (h0, h1), h1 in {0,1,2}
-        u64 add1 = (u64)ce0 + ((u64)co << 32);  // < 2^64 since co < 2^31
-        u64 h0 = e23 + add1;
-        u64 h1 = h0 < add1;
-        // m = l1 + h0 as (m0, m1)
-        u64 m0 = l1 + h0;
-        u64 m1 = m0 < h0;
-        u64 top = m1 + h1 + ce2;  // multiples of 2^128
-        u64 r = canon(red128(m0, l0));
-        u64 t = top << 32;        // canonical: top is tiny
-        return r >= t ? r - t : r + (gl::P - t);
+        u32 k1, k2, k2b, k3, k3b, b, b2;
+        const u32 L0 = (u32)e01;
+        const u32 L1 = __builtin_addc((u32)(e01 >> 32), (u32)o01, 0u, &k1);
+        u32 L2 = __builtin_addc((u32)(o01 >> 32), (u32)e23, k1, &k2);
+        L2 = __builtin_addc(L2, ce0, 0u, &k2b);
+        u32 L3 = __builtin_addc((u32)(e23 >> 32), co, k2, &k3);
+        L3 = __builtin_addc(L3, 0u, k2b, &k3b);
+        const u32 L4 = ce2 + k3 + k3b;  // multiples of 2^128: tiny
+        const u64 r = red128(((u64)L3 << 32) | L2, ((u64)L1 << 32) | L0);
+        // r - L4 * 2^32; a borrow is worth -2^64 = -(2^32 - 1)
+        const u32 h1 = __builtin_subc((u32)(r >> 32), L4, 0u, &b);
+        const u32 lo = __builtin_subc((u32)r, 0u - b, 0u, &b2);
+        return ((u64)(h1 - b2) << 32) | lo;
     }
 };
 
@@ -195,9 +194,12 @@ GL_HD void poseidon(u64* s) {
         for (int j = 0; j < 11; j++) {
             u64 ph, pl;
             mul128(PF_V[i * 11 + j], s0, ph, pl);
-            pl += s[1 + j];
-            ph += pl < s[1 + j];
-            s[1 + j] = red128(ph, pl);
+            u32 k0, k1, k2;  // (ph, pl) += s[1 + j] as one carry chain (a u64 compare for the carry costs more)
+            const u32 a0 = __builtin_addc((u32)pl, (u32)s[1 + j], 0u, &k0);
+            const u32 a1 = __builtin_addc((u32)(pl >> 32), (u32)(s[1 + j] >> 32), k0, &k1);
+            const u32 a2 = __builtin_addc((u32)ph, 0u, k1, &k2);
+            const u32 a3 = (u32)(ph >> 32) + k2;
+            s[1 + j] = red128(((u64)a3 << 32) | a2, ((u64)a1 << 32) | a0);
         }
         s[0] = a.reduce();
     }
