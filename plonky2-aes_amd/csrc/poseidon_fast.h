@@ -52,8 +52,15 @@ GL_HD u64 red128(u64 hi, u64 lo) {
     const u32 net = 0u - mC - B;                     // C - B
     w1 += net;                                       // + net * 2^32
     const u32 sx = (u32)((int)net >> 31);
-    const u32 r0 = __builtin_subc(w0, net, 0u, &b);  // - net (sign-extended)
-    const u32 r1 = __builtin_subc(w1, sx, b, &B);
+    u32 r0 = __builtin_subc(w0, net, 0u, &b);        // - net (sign-extended)
+    u32 r1 = __builtin_subc(w1, sx, b, &B);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Value barrier.  ROCm 7.2's AMDGPU backend folds "x - borrow" into a following add-with-carry as "+ 0xFFFFFFFF", which
+    // keeps the sum but not the carry-out: a reduction whose result feeds an add-with-carry chain in the same basic block
+    // was miscompiled that way (tools/microbench/reduce_check.hip shows it: 4.7 % wrong results when a carry-based
+    // canonicalisation follows directly).  The empty asm makes r0, r1 opaque to that combine; it emits nothing.
+    asm("" : "+v"(r0), "+v"(r1));
+#endif
     return ((u64)r1 << 32) | r0;
 }
 GL_HD u64 mulr(u64 a, u64 b) {
@@ -123,8 +130,12 @@ struct Acc {
         const u64 r = red128(((u64)L3 << 32) | L2, ((u64)L1 << 32) | L0);
         // r - L4 * 2^32; a borrow is worth -2^64 = -(2^32 - 1)
         const u32 h1 = __builtin_subc((u32)(r >> 32), L4, 0u, &b);
-        const u32 lo = __builtin_subc((u32)r, 0u - b, 0u, &b2);
-        return ((u64)(h1 - b2) << 32) | lo;
+        u32 lo = __builtin_subc((u32)r, 0u - b, 0u, &b2);
+        u32 hi = h1 - b2;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+v"(lo), "+v"(hi));  // value barrier, see red128
+#endif
+        return ((u64)hi << 32) | lo;
     }
 };
 
