@@ -3,6 +3,8 @@
 //     product is reduced once from 128 bits without the final conditional subtraction; outputs are canonicalised;
 //   * the 22 partial rounds use the sparse-matrix form derived by tools/gen_poseidon_fast.py: 23 multiply-accumulates
 //     per round instead of a 144-term MDS, with the 12-term dot product accumulated in 192 bits and reduced once.
+//   * reductions, the accumulator fold and the 128-bit add of the partial rounds are carry chains on 32-bit halves: a
+//     64-bit compare-and-select costs 5.5 issue slots on gfx950 and the textbook reduce128 has two of them.
 // Measured on MI355X (tools/microbench/int_rates.hip): v_mad_u64_u32 issues at ~1.8x the cost of a simple VALU op,
 // so the win comes from removing instructions, not from swapping multiply flavours.
 #pragma once
