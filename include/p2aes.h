@@ -159,6 +159,12 @@ int p2_builder_elgamal_encrypt(p2_builder*, const p2_target pk[10], const p2_tar
 int p2_builder_hashed_elgamal_encrypt(p2_builder*, const p2_target pk[10], const p2_target nonce_bits[320], const p2_target msg[5],
                                       p2_target c0[10], p2_target ct[5]);
 
+/* ------------------------------------------------------------------ self-test (host) */
+/* Checks the host build of the arithmetic the kernels share with it: the carry-chain reduction against 128-bit
+ * arithmetic (random and extreme inputs), and the restructured Poseidon (poseidon_fast.h: lazy reduction, sparse partial
+ * rounds, accumulator fold) against the plain 30-round permutation.  0 = all agree; otherwise the number of mismatches. */
+int p2_selftest_host(uint64_t seed, size_t n_reductions, size_t n_permutations);
+
 /* ------------------------------------------------------------------ native cipher (host; witness values) */
 uint8_t p2_native_gf_2_8_mul(uint8_t a, uint8_t b);
 void p2_native_aes_key_expansion(const uint8_t* key, int nk, int nr, uint8_t* out /* 16*(nr+1) */);

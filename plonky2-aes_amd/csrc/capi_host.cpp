@@ -7,6 +7,7 @@
 #include "capi_common.h"
 #include "ecgfp5.h"
 #include "poseidon_cipher.h"
+#include "poseidon_fast.h"
 #include "verifier.h"
 
 using namespace p2;
@@ -343,6 +344,51 @@ int p2_builder_hashed_elgamal_encrypt(p2_builder* b, const p2_target pk[10], con
     } catch (std::exception& e) {
         return set_error(e.what()), P2_ERR_INVALID;
     }
+}
+
+// ---- self-test
+int p2_selftest_host(uint64_t seed, size_t n_reductions, size_t n_permutations) {
+    u64 x = seed | 1;
+    auto rnd = [&]() {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        return x;
+    };
+    size_t bad = 0;
+    for (size_t i = 0; i < n_reductions; i++) {
+        u64 hi = rnd(), lo = rnd();
+        switch (i & 15) {
+            case 0: hi &= gl::EPS; break;
+            case 1: lo &= gl::EPS; break;
+            case 2: hi |= ~gl::EPS; break;
+            case 3: lo |= ~gl::EPS; break;
+            case 4: hi = 0; break;
+            case 5: lo = 0; break;
+            case 6: hi = ~0ull; lo = ~0ull - (x & 3); break;
+            case 7: hi &= ~gl::EPS; lo &= gl::EPS; break;
+            default: break;
+        }
+        unsigned __int128 v = ((unsigned __int128)hi << 64) | lo;
+        u64 want = (u64)(v % gl::P);
+        if (glf::canon(glf::red128(hi, lo)) != want) bad++;
+        if (gl::reduce128(hi, lo) != want) bad++;
+        glf::Acc a;
+        a.init();
+        a.fma(hi, lo);
+        a.fma(lo, lo);
+        unsigned __int128 w = ((unsigned __int128)hi * lo) % gl::P + ((unsigned __int128)lo * lo) % gl::P;
+        if (glf::canon(a.reduce()) != (u64)(w % gl::P)) bad++;
+    }
+    for (size_t i = 0; i < n_permutations; i++) {
+        u64 s0[12], s1[12];
+        for (int k = 0; k < 12; k++) s0[k] = s1[k] = (i & 3) == 3 ? rnd() : rnd() % gl::P;  // canonical or arbitrary words
+        for (int k = 0; k < 12; k++) s0[k] %= gl::P;
+        gl::poseidon(s0);
+        glf::poseidon(s1);
+        for (int k = 0; k < 12; k++) bad += s0[k] != s1[k];
+    }
+    return (int)std::min<size_t>(bad, 0x7FFFFFFF);
 }
 
 // ---- native cipher

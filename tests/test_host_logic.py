@@ -402,3 +402,12 @@ def test_blob_mutation_fuzz_never_crashes(pkg):
             rc = pkg.lib().p2_blob_info(bytes(b), len(b), C.byref(info))
             rejected += rc != 0
     assert rejected > 200
+
+
+def test_host_selftest_of_the_shared_arithmetic(pkg):
+    """poseidon_fast.h (lazy carry-chain reductions, sparse partial rounds, accumulator fold) is the arithmetic the hashing
+    kernels run; its host build must agree with 128-bit arithmetic and with the plain permutation.  (The device build is
+    cross-checked by tools/microbench/reduce_check.hip and poseidon_bench.hip and by every GPU parity test.)"""
+    assert pkg.lib().p2_selftest_host(0x5EED, 2_000_000, 2_000) == 0
+    assert pkg.lib().p2_selftest_host(7, 200_000, 500) == 0
+
