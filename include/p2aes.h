@@ -164,6 +164,10 @@ int p2_builder_hashed_elgamal_encrypt(p2_builder*, const p2_target pk[10], const
  * arithmetic (random and extreme inputs), and the restructured Poseidon (poseidon_fast.h: lazy reduction, sparse partial
  * rounds, accumulator fold) against the plain 30-round permutation.  0 = all agree; otherwise the number of mismatches. */
 int p2_selftest_host(uint64_t seed, size_t n_reductions, size_t n_permutations);
+/* The same comparison compiled for the device and run there (threads x 64 reductions and threads x 1 permutation,
+ * textbook forms as the reference): guards against code-generation regressions such as the add-with-carry fold described
+ * in DESIGN.md.  Returns the number of mismatches, or a negative P2_ERR_* code. */
+int p2_selftest_device(uint64_t seed, size_t threads, int device);
 
 /* ------------------------------------------------------------------ native cipher (host; witness values) */
 uint8_t p2_native_gf_2_8_mul(uint8_t a, uint8_t b);

@@ -114,7 +114,7 @@ def lib():
         "p2_builder_public_key": (C.c_int, [vp, u64p, u64p]),
         "p2_builder_elgamal_encrypt": (C.c_int, [vp, u64p, u64p, u64p, u64p, u64p]),
         "p2_builder_hashed_elgamal_encrypt": (C.c_int, [vp, u64p, u64p, u64p, u64p, u64p]),
-        "p2_selftest_host": (C.c_int, [u64, sz, sz]),
+        "p2_selftest_host": (C.c_int, [u64, sz, sz]), "p2_selftest_device": (C.c_int, [u64, sz, C.c_int]),
         "p2_native_gf_2_8_mul": (C.c_uint8, [C.c_uint8, C.c_uint8]),
         "p2_native_aes_key_expansion": (None, [C.c_char_p, C.c_int, C.c_int, C.c_char_p]),
         "p2_native_aes_encrypt_block": (None, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p]),

@@ -1215,6 +1215,74 @@ static int pick_device(int device) {
     HIPCHECK(hipSetDevice(device));
     return 0;
 }
+// ---- device self-test
+namespace p2k {
+__global__ void k_selftest(unsigned long long* bad, u64 seed, size_t threads) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= threads) return;
+    u64 x = (seed | 1) + 0x9E3779B97F4A7C15ull * (t + 1);
+    auto rnd = [&]() {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        return x;
+    };
+    unsigned long long b = 0;
+    for (int i = 0; i < 64; i++) {
+        u64 hi = rnd(), lo = rnd();
+        const int m = i & 15;
+        if (m == 0) hi &= gl::EPS;
+        if (m == 1) lo &= gl::EPS;
+        if (m == 2) hi |= ~gl::EPS;
+        if (m == 3) lo |= ~gl::EPS;
+        if (m == 4) hi = 0;
+        if (m == 5) lo = 0;
+        if (m == 6) {
+            hi = ~0ull;
+            lo = ~0ull - (x & 3);
+        }
+        if (m == 7) {
+            hi &= ~gl::EPS;
+            lo &= gl::EPS;
+        }
+        const u64 want = gl::reduce128(hi, lo);  // textbook form
+        if (glf::canon(glf::red128(hi, lo)) != want) b++;
+        glf::Acc a;
+        a.init();
+        a.fma(hi, lo);
+        a.fma(lo, lo);
+        if (glf::canon(a.reduce()) != gl::add(gl::mul(hi % gl::P, lo % gl::P), gl::mul(lo % gl::P, lo % gl::P))) b++;
+        // a carry-consuming chain right after a reduction: the pattern the backend used to break
+        const u64 r = glf::red128(hi, lo);
+        u32 k, K;
+        const u32 c0 = __builtin_addc((u32)r, 0xFFFFFFFFu, 0u, &k);
+        const u32 c1 = __builtin_addc((u32)(r >> 32), 0u, k, &K);
+        if ((K ? (((u64)c1 << 32) | c0) : r) != want) b++;
+    }
+    u64 s0[12], s1[12];
+    for (int k = 0; k < 12; k++) {
+        s1[k] = (t & 3) == 3 ? rnd() : rnd() % gl::P;
+        s0[k] = s1[k] % gl::P;
+    }
+    gl::poseidon(s0);
+    glf::poseidon(s1);
+    for (int k = 0; k < 12; k++) b += s0[k] != s1[k];
+    if (b) atomicAdd(bad, b);
+}
+}  // namespace p2k
+
+int p2_selftest_device(uint64_t seed, size_t threads, int device) {
+    if (hipSetDevice(device) != hipSuccess) return set_error("no such HIP device"), -P2_ERR_HIP;
+    unsigned long long* d = nullptr;
+    if (hipMalloc((void**)&d, 8) != hipSuccess || hipMemset(d, 0, 8) != hipSuccess) return set_error("hipMalloc failed"), -P2_ERR_HIP;
+    hipLaunchKernelGGL(p2k::k_selftest, dim3((u32)((threads + 255) / 256)), dim3(256), 0, 0, d, (u64)seed, threads);
+    unsigned long long h = 0;
+    hipError_t e = hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return set_error(hipGetErrorString(e)), -P2_ERR_HIP;
+    return (int)std::min<unsigned long long>(h, 0x7FFFFFFF);
+}
+
 int p2_gpu_poseidon(uint64_t* states, size_t n_perm, int device) {
     if (int rc = pick_device(device)) return rc;
     u64* d;

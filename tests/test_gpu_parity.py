@@ -30,6 +30,12 @@ def test_native_library_is_the_in_tree_hip_build(gpu):
     assert "libp2aes.so" in maps
 
 
+def test_device_selftest_of_the_shared_arithmetic(gpu):
+    """Carry-chain reductions, the accumulator fold and the restructured Poseidon, compiled for gfx950, against the
+    textbook forms on the device: 2^20 threads x 64 reductions (random and extreme halves) and one permutation each."""
+    assert gpu.lib().p2_selftest_device(0x5EED, 1 << 20, 0) == 0
+
+
 def test_poseidon_permutation(gpu, orc):
     r = random.Random(11)
     n = 5000
