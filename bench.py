@@ -82,6 +82,30 @@ def kernel_bytes(name, info, active_wires=80):
     return None
 
 
+def spawn_ranks(n):
+    """One process per GPU on this node: python -m torch.distributed.run --nproc-per-node n bench.py <same argv>."""
+    import socket
+    import subprocess
+    with socket.socket() as so:  # a free rendezvous port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def device_identity(torch, index):
+    """PCI bus id (or uuid) of the device this rank proves on: the driver can see N distinct GPUs in the JSON line."""
+    p = torch.cuda.get_device_properties(index)
+    dom, bus, dev = (getattr(p, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    if bus is not None:
+        return "%04x:%02x:%02x.0" % (dom or 0, bus, dev or 0)
+    return str(getattr(p, "uuid", index))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +118,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=5, help="proofs timed on the host for cpu_baseline (median, after one warm-up)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD torch.distributed.run (never an
+    # exec -- and before anything in this process touches the GPU), relay rank 0's JSON line and leave with the child's code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import torch
     import __graft_entry__ as g
@@ -119,6 +148,11 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    ident = device_identity(torch, local_rank)
+    devices = [ident]
+    if dist:
+        devices = [None] * world
+        dist.all_gather_object(devices, ident)
 
     L, B = args.plaintext_bytes, args.batch
     if L > 4096 and args.batch == 256:
@@ -262,7 +296,7 @@ def main():
                       "note": "SURVEY.md 8(d) formula with this build's column counts; the path is Poseidon/VALU bound, see roofline.note"}
         out = {
             "metric": metric, "value": round(total_proofs / dt, 3), "unit": "proofs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "n_gpus": world, "ranks_seen": dist.get_world_size() if dist else 1, "devices": devices, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks field)", "data": "synthetic",
             "config": {"workload": label, "proofs_per_step_per_gpu": B, "proof_bytes": pb, "parallelism": "independent proofs sharded by index"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,

@@ -44,7 +44,8 @@ enum {
     P2_PROOF_OK = 0,
     P2_PROOF_WITNESS_CONFLICT = 1, /* generator output conflicts with a pre-set target, or lookup input not in table */
     P2_PROOF_MISSING_INPUT = 2,    /* some generator never ran: an input target was not set */
-    P2_PROOF_ZETA_IN_SUBGROUP = 3  /* "Opening point is in the subgroup." */
+    P2_PROOF_ZETA_IN_SUBGROUP = 3, /* "Opening point is in the subgroup." */
+    P2_PROOF_POW_NOT_FOUND = 4     /* no proof-of-work witness among the 2^21 candidates searched (probability ~e^-32) */
 };
 
 const char* p2_last_error(void);
@@ -133,10 +134,16 @@ void p2_ecgfp5_neg(const uint64_t p[10], uint64_t out[10]);      /* Point::inver
 int p2_ecgfp5_is_in_subgroup(const uint64_t p[10]);              /* 1 / 0 */
 void p2_ecgfp5_compress(const uint64_t p[10], uint64_t w[5]);    /* compress_from_subgroup (lib.rs:82) */
 int p2_ecgfp5_decompress(const uint64_t w[5], uint64_t out[10]); /* decompress_into_subgroup (lib.rs:74); P2_ERR_INVALID if none */
-void p2_ecgfp5_random_scalar(uint64_t seed, uint64_t out[5]);    /* gen_biguint_below(&GROUP_ORDER), seeded (upstream: OsRng) */
-void p2_ecgfp5_random_point(uint64_t seed, uint64_t out[10]);    /* Point::new_rand_from_subgroup, seeded */
-/* encode_binary / decode_binary (lib.rs:48, :80): 160 message bits as five 32-bit limbs */
-void p2_ecgfp5_encode_binary(const uint32_t limbs[5], uint64_t seed, uint64_t out[10]);
+/* Randomness comes from the operating system's CSPRNG, as the reference's OsRng (lib.rs:35,64): */
+int p2_ecgfp5_random_scalar(uint64_t out[5]);                    /* gen_biguint_below(&GROUP_ORDER) (lib.rs:35) */
+int p2_ecgfp5_random_point(uint64_t out[10]);                    /* Point::new_rand_from_subgroup */
+/* encode_binary / decode_binary (lib.rs:48, :80): 160 message bits as five 32-bit limbs, random padding above them */
+int p2_ecgfp5_encode_binary(const uint32_t limbs[5], uint64_t out[10]);
+/* TEST / BENCHMARK ONLY: the same three from a 64-bit seed (SplitMix64, not cryptographic) so that inputs are
+ * reproducible.  A scalar drawn this way carries at most 64 bits of entropy: never a real key or nonce. */
+void p2_ecgfp5_random_scalar_seeded(uint64_t seed, uint64_t out[5]);
+void p2_ecgfp5_random_point_seeded(uint64_t seed, uint64_t out[10]);
+void p2_ecgfp5_encode_binary_seeded(const uint32_t limbs[5], uint64_t seed, uint64_t out[10]);
 void p2_ecgfp5_decode_binary(const uint64_t p[10], uint32_t limbs[5]);
 /* elgamal.rs:11, :19; hashed_elgamal.rs:19, :28.  Scalars must be below the group order (P2_ERR_INVALID otherwise). */
 int p2_elgamal_encrypt(const uint64_t pk[10], const uint64_t nonce[5], const uint64_t msg[10], uint64_t c0[10], uint64_t c1[10]);
@@ -185,6 +192,7 @@ typedef struct {
     uint32_t degree_bits, num_wires, num_routed_wires, num_constants_cols, num_zs_cols, num_quotient_cols, num_luts,
         num_ops, num_levels, num_slots, num_virtual_targets, num_fri_rounds;
     uint64_t proof_bytes; /* exact serialised proof size */
+    uint32_t zero_knowledge, num_gate_kinds; /* standard_recursion_zk_config(); distinct gate types in the circuit */
 } p2_circuit_info;
 int p2_blob_info(const uint8_t* blob, size_t len, p2_circuit_info* out);
 /* verifier_data = constants_sigmas_cap (16 digests) || circuit_digest, 68 u64 -- from p2_circuit_verifier_data */
@@ -197,8 +205,13 @@ typedef struct p2_circuit p2_circuit;
 p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device);
 void p2_circuit_free(p2_circuit*);
 int p2_circuit_verifier_data(const p2_circuit*, uint64_t* out, size_t cap, size_t* n_written);
-/* zk circuits only: blinding values are a keyed function of (seed, index of the proof since the seed was set), so a
- * run is reproducible; the default seed is drawn from the OS at load time (upstream: OS randomness per proof). */
+/* zk circuits only.  Blinding values are the output of a Poseidon-based PRF under a 256-bit key (four field elements)
+ * and a per-handle proof counter that advances with every proof attempted.  The key is drawn from the operating system's
+ * CSPRNG at load time (upstream: OS randomness per proof) -- that is the production path and needs no call here.
+ * TEST ONLY: p2_circuit_set_zk_key fixes the key (words are reduced mod p) and resets the counter, which makes proofs
+ * reproducible so the CPU oracle can check them byte for byte; p2_circuit_set_zk_seed(s) is set_zk_key({s, 0, 0, 0}).
+ * A fixed key is not secret: never use either outside tests and benchmarks. */
+int p2_circuit_set_zk_key(p2_circuit*, const uint64_t key[4]);
 int p2_circuit_set_zk_seed(p2_circuit*, uint64_t seed);
 size_t p2_circuit_proof_bytes(const p2_circuit*);
 /* One PartialWitness: (target, value) pairs, values canonical (< p). */
@@ -208,8 +221,12 @@ typedef struct {
     size_t count;
 } p2_assignment;
 /* Proves `batch` independent witnesses of one circuit.  proofs: batch * p2_circuit_proof_bytes() bytes.
- * status[i] receives a P2_PROOF_* code; a failed proof leaves its slot zeroed.  The call returns after the
- * proofs are in host memory.  Safe to call concurrently on different p2_circuit handles. */
+ * status[i] receives a P2_PROOF_* code; a failed proof leaves its slot zeroed (a value >= p fails its witness with
+ * P2_PROOF_WITNESS_CONFLICT, like a conflicting set_target).  The call returns after the proofs are in host memory.
+ * Inputs and proofs travel through persistent pinned staging buffers owned by the handle.
+ * Thread safety: `prove(&self)` in the reference takes a shared reference, and so does this: any number of host threads
+ * may call p2_prove_batch / p2_prove_batch_device concurrently on the SAME handle (enqueueing is serialised inside; each
+ * caller gets its own staging set) as well as on different handles. */
 int p2_prove_batch(p2_circuit*, size_t batch, const p2_assignment* inputs, uint8_t* proofs, int* status);
 /* Same pipeline with inputs already resident on the device and proofs left on the device:
  * d_values: [batch][n_targets] u64 (device pointer), targets shared by the whole batch (host pointer); the value
@@ -222,6 +239,10 @@ int p2_prove_batch(p2_circuit*, size_t batch, const p2_assignment* inputs, uint8
 int p2_prove_batch_device(p2_circuit*, size_t batch, const p2_target* targets, size_t n_targets, const uint64_t* d_values,
                           uint8_t* d_proofs, int* d_status, void* stream);
 int p2_circuit_synchronize(p2_circuit*);
+/* Tuning knobs of a handle: "chunk" (proofs per workspace, default 128), "streams" (proving streams, default 2),
+ * "debug_timing" (host-path phase times on stderr).  The environment variables P2AES_CHUNK / P2AES_STREAMS /
+ * P2AES_DEBUG_TIMING set the defaults and are read once, in p2_circuit_load. */
+int p2_circuit_set_option(p2_circuit*, const char* name, long value);
 /* Per-kernel timing of the most recent batch (HIP events on the proving stream). */
 typedef struct {
     char name[48];

@@ -60,10 +60,14 @@ void orc_get_op(void* hp, size_t i, uint32_t* kind, uint32_t* out) {
     *kind = c->ops[i].kind;
     *out = c->ops[i].out;
 }
-// zk circuits: blinding seed and index of the next proof (same keyed RNG as the product)
-void orc_set_zk(void* hp, uint64_t seed, uint64_t proof_index) {
-    ((Handle*)hp)->c->zk_seed = seed;
+// zk circuits: blinding key (four field elements) and index of the next proof under it
+void orc_set_zk_key(void* hp, const uint64_t* key4, uint64_t proof_index) {
+    for (int i = 0; i < 4; i++) ((Handle*)hp)->c->zk_key[i] = key4[i] % MODULUS;
     ((Handle*)hp)->c->zk_proof = proof_index;
+}
+void orc_set_zk(void* hp, uint64_t seed, uint64_t proof_index) {  // the product's p2_circuit_set_zk_seed: key = {seed, 0, 0, 0}
+    const uint64_t key[4] = {seed, 0, 0, 0};
+    orc_set_zk_key(hp, key, proof_index);
 }
 // verifier-only data: constants_sigmas_cap (2^cap_height digests) followed by circuit_digest; returns #u64
 size_t orc_verifier_data(void* hp, uint64_t* out, size_t cap) {

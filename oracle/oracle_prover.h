@@ -23,20 +23,25 @@ struct OConfig {
     u32 num_wires, num_routed_wires, num_constants, num_challenges, quotient_degree_factor, rate_bits, cap_height, pow_bits,
         num_query_rounds, arity_bits, final_poly_bits, zero_knowledge;
 };
-// keyed blinding randomness, shared definition with the product (circuit.h zk_rand): SplitMix64 finaliser mod p
-static inline u64 zk_rand(u64 seed, u64 proof, u64 domain, u64 index) {
-    u64 x = seed ^ (proof * 0x9E3779B97F4A7C15ull) ^ (domain << 56);
-    for (int round = 0; round < 2; round++) {
-        x += 0x9E3779B97F4A7C15ull + (round ? index : 0);
-        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-        x ^= x >> 31;
-        x ^= index * 0xD6E8FEB86659FD93ull;
+// Blinding PRF of the zk configuration, restated from its definition (product: csrc/circuit.h "Blinding randomness"):
+// element `index` of (proof, domain) = Poseidon(key[0..4] | proof | domain | index / 8 | TAG | 0^4)[index % 8].
+// Sequential callers hit the one-block cache.
+struct ZkStream {
+    u64 key[4], proof, domain;
+    u64 block = ~0ull, out[8];
+    ZkStream(const u64* k, u64 proof_, u64 domain_) : proof(proof_), domain(domain_) {
+        for (int i = 0; i < 4; i++) key[i] = k[i];
     }
-    x = (x ^ (x >> 32)) * 0xD6E8FEB86659FD93ull;
-    x ^= x >> 29;
-    return x % MODULUS;
-}
+    u64 at(u64 index) {
+        if ((index >> 3) != block) {
+            block = index >> 3;
+            u64 st[12] = {key[0], key[1], key[2], key[3], proof, domain, block, 0x7a6b5f626c696e64ull % MODULUS, 0, 0, 0, 0};
+            poseidon_permute(st);
+            for (int i = 0; i < 8; i++) out[i] = st[i];
+        }
+        return out[index & 7];
+    }
+};
 struct OOp {
     u32 kind, out, a, b, c, aux;
     u64 k0, k1;
@@ -91,7 +96,7 @@ struct OCircuit {
     std::vector<int32_t> vt_slot, wire_slot;
     std::vector<u32> poseidon_rows, blind_rows;
     std::vector<std::pair<u32, u32>> blind_zrows;
-    u64 zk_seed = 0, zk_proof = 0;  // set per proof by the caller (orc_set_zk)
+    u64 zk_key[4] = {0, 0, 0, 0}, zk_proof = 0;  // set per proof by the caller (orc_set_zk / orc_set_zk_key)
     // fault injection (soundness tests): after witness generation add `fault_delta` to a slot (every copy of the value:
     // only gate / lookup constraints can notice) or to one wire cell (the permutation argument must notice)
     int fault_kind = 0;  // 0 none, 1 slot, 2 wire cell
@@ -133,8 +138,11 @@ static inline void commit_from_coeffs(const OCircuit& C, Batch& b, int oracle_in
         std::vector<u64> v = coset_fft(b.coeffs[c], C.lde_bits, GENERATOR);
         for (size_t i = 0; i < N; i++) b.lde[rev_bits(i, C.lde_bits) * b.width + c] = v[i];
     }
-    for (size_t s = 0; s < salt; s++)
-        for (size_t pos = 0; pos < N; pos++) b.lde[pos * b.width + cols + s] = zk_rand(C.zk_seed, C.zk_proof, 3 + oracle_index, s * N + pos);
+    if (salt) {
+        ZkStream zs(C.zk_key, C.zk_proof, 3 + oracle_index);
+        for (size_t s = 0; s < salt; s++)
+            for (size_t pos = 0; pos < N; pos++) b.lde[pos * b.width + cols + s] = zs.at(s * N + pos);
+    }
     b.tree = build_merkle(b.lde.data(), N, b.width, C.cfg.cap_height);
 }
 static inline void commit_from_values(const OCircuit& C, Batch& b, const std::vector<std::vector<u64>>& values, int oracle_index) {
@@ -333,11 +341,12 @@ static inline int generate_witness(const OCircuit& C, const u64* in_targets, con
             }
         }
     // zk blinding rows (RandomValueGenerators of blind_and_pad)
+    ZkStream zrow(C.zk_key, C.zk_proof, 1), zzrow(C.zk_key, C.zk_proof, 2);
     for (size_t k = 0; k < C.blind_rows.size(); k++)
-        for (size_t c = 0; c < C.cfg.num_wires; c++) wires[c][C.blind_rows[k]] = zk_rand(C.zk_seed, C.zk_proof, 1, k * C.cfg.num_wires + c);
+        for (size_t c = 0; c < C.cfg.num_wires; c++) wires[c][C.blind_rows[k]] = zrow.at(k * C.cfg.num_wires + c);
     for (size_t k = 0; k < C.blind_zrows.size(); k++)
         for (size_t c = 0; c < R; c++) {
-            u64 v = zk_rand(C.zk_seed, C.zk_proof, 2, k * R + c);
+            u64 v = zzrow.at(k * R + c);
             wires[c][C.blind_zrows[k].first] = v;
             wires[c][C.blind_zrows[k].second] = v;
         }

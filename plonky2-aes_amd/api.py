@@ -28,7 +28,8 @@ class ProveError(P2Error):
     def __init__(self, status):
         self.status = status
         super().__init__({1: "witness conflict or lookup input not in table", 2: "a generator never ran (missing input)",
-                          3: "opening point is in the subgroup"}.get(status, "prove failed (%d)" % status))
+                          3: "opening point is in the subgroup",
+                          4: "no proof-of-work witness found"}.get(status, "prove failed (%d)" % status))
 
 
 u32p = C.POINTER(C.c_uint32)
@@ -45,7 +46,8 @@ u64, u8p, u64p, u16p, sz = C.c_uint64, C.POINTER(C.c_uint8), C.POINTER(C.c_uint6
 class _Info(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("degree_bits", "num_wires", "num_routed_wires", "num_constants_cols", "num_zs_cols",
                                            "num_quotient_cols", "num_luts", "num_ops", "num_levels", "num_slots",
-                                           "num_virtual_targets", "num_fri_rounds")] + [("proof_bytes", C.c_uint64)]
+                                           "num_virtual_targets", "num_fri_rounds")] + [("proof_bytes", C.c_uint64), ("zero_knowledge", C.c_uint32),
+                                                                                      ("num_gate_kinds", C.c_uint32)]
 
 
 class _Assignment(C.Structure):
@@ -70,6 +72,8 @@ def lib():
         "p2_last_error": (C.c_char_p, []),
         "p2_builder_new": (vp, []), "p2_builder_new_zk": (vp, []), "p2_builder_free": (None, [vp]),
         "p2_circuit_set_zk_seed": (C.c_int, [vp, u64]),
+        "p2_circuit_set_zk_key": (C.c_int, [vp, C.POINTER(u64)]),
+        "p2_circuit_set_option": (C.c_int, [vp, C.c_char_p, C.c_long]),
         "p2_builder_add_virtual_target": (u64, [vp]), "p2_builder_constant": (u64, [vp, u64]),
         "p2_builder_zero": (u64, [vp]), "p2_builder_one": (u64, [vp]),
         "p2_builder_arithmetic": (u64, [vp, u64, u64, u64, u64, u64]),
@@ -103,8 +107,10 @@ def lib():
         "p2_ecgfp5_mul": (None, [u64p, u64p, u64p]), "p2_ecgfp5_add": (None, [u64p, u64p, u64p]), "p2_ecgfp5_neg": (None, [u64p, u64p]),
         "p2_ecgfp5_is_in_subgroup": (C.c_int, [u64p]),
         "p2_ecgfp5_compress": (None, [u64p, u64p]), "p2_ecgfp5_decompress": (C.c_int, [u64p, u64p]),
-        "p2_ecgfp5_random_scalar": (None, [u64, u64p]), "p2_ecgfp5_random_point": (None, [u64, u64p]),
-        "p2_ecgfp5_encode_binary": (None, [u32p, u64, u64p]), "p2_ecgfp5_decode_binary": (None, [u64p, u32p]),
+        "p2_ecgfp5_random_scalar": (C.c_int, [u64p]), "p2_ecgfp5_random_point": (C.c_int, [u64p]),
+        "p2_ecgfp5_encode_binary": (C.c_int, [u32p, u64p]),
+        "p2_ecgfp5_random_scalar_seeded": (None, [u64, u64p]), "p2_ecgfp5_random_point_seeded": (None, [u64, u64p]),
+        "p2_ecgfp5_encode_binary_seeded": (None, [u32p, u64, u64p]), "p2_ecgfp5_decode_binary": (None, [u64p, u32p]),
         "p2_elgamal_encrypt": (C.c_int, [u64p, u64p, u64p, u64p, u64p]), "p2_elgamal_decrypt": (C.c_int, [u64p, u64p, u64p, u64p]),
         "p2_hashed_elgamal_encrypt": (C.c_int, [u64p, u64p, u64p, u64p, u64p]),
         "p2_hashed_elgamal_decrypt": (C.c_int, [u64p, u64p, u64p, u64p]),
@@ -364,6 +370,7 @@ class CircuitData:
         self.blob = blob
         self.device = device
         self._gpu = None
+        self._vd = None
         info = _Info()
         if lib().p2_blob_info(blob, len(blob), C.byref(info)):
             raise P2Error(_err())
@@ -386,11 +393,20 @@ class CircuitData:
     def proof_bytes(self): return self.info["proof_bytes"]
 
     def verifier_data(self):
-        out = (u64 * 80)()
-        n = sz()
-        if lib().p2_circuit_verifier_data(self.gpu(), out, 80, C.byref(n)):
+        """constants_sigmas_cap || circuit_digest.  Computed on the device when the circuit is loaded (the reference's
+        build() computes it); cached here, so verify() of later proofs needs no device."""
+        if self._vd is None:
+            out = (u64 * 80)()
+            n = sz()
+            if lib().p2_circuit_verifier_data(self.gpu(), out, 80, C.byref(n)):
+                raise P2Error(_err())
+            self._vd = list(out[: n.value])
+        return list(self._vd)
+
+    def set_option(self, name, value):
+        """Tuning knobs of the GPU handle: "chunk", "streams", "debug_timing" (include/p2aes.h)."""
+        if lib().p2_circuit_set_option(self.gpu(), name.encode(), int(value)):
             raise P2Error(_err())
-        return list(out[: n.value])
 
     def prove_batch(self, pws):
         """Returns (proofs: list[bytes|None], status: list[int])."""
@@ -416,7 +432,13 @@ class CircuitData:
             raise P2Error("p2_prove_batch_device failed: " + _err())
 
     def set_zk_seed(self, seed):
+        """TEST ONLY (reproducible zk proofs): blinding key = (seed, 0, 0, 0).  The default key comes from the OS CSPRNG."""
         if lib().p2_circuit_set_zk_seed(self.gpu(), seed):
+            raise P2Error(_err())
+
+    def set_zk_key(self, key4):
+        """TEST ONLY: fix the full 256-bit blinding key (four field elements) and reset the proof counter."""
+        if lib().p2_circuit_set_zk_key(self.gpu(), (C.c_uint64 * 4)(*key4)):
             raise P2Error(_err())
 
     def synchronize(self):
@@ -501,12 +523,12 @@ class poseidon_native:
         return list(out)
 
     @staticmethod
-    def new_key(seed):                                     # lib.rs:31 (seeded; upstream OsRng)
+    def new_key(seed=None):                                # lib.rs:31 (OS randomness, as upstream's OsRng; seed = tests only)
         k = ecgfp5.random_scalar(seed)
         return k, ecgfp5.mul(k, ecgfp5.generator())
 
     @staticmethod
-    def expanded_key(K, seed):                             # lib.rs:36
+    def expanded_key(K, seed=None):                        # lib.rs:36
         return ecgfp5.mul(ecgfp5.random_scalar(seed), K)
 
     @staticmethod
@@ -539,7 +561,7 @@ def _sc(k):
 
 class ecgfp5:
     """The ecgfp5 crate's native side (ecgfp5/src/lib.rs, elgamal.rs, hashed_elgamal.rs) through the C ABI.  A Point is
-    ((x0..x4), (u0..u4)); scalars are Python ints.  Randomness takes an explicit seed where upstream reads OsRng."""
+    ((x0..x4), (u0..u4)); scalars are Python ints.  Randomness comes from the OS CSPRNG as upstream's OsRng; an explicit seed (tests only) makes it reproducible."""
 
     @staticmethod
     def group_order():
@@ -588,22 +610,37 @@ class ecgfp5:
         return _pt_out(out)
 
     @staticmethod
-    def random_scalar(seed):
+    def random_scalar(seed=None):
+        """Uniform scalar below the group order from the OS CSPRNG; a `seed` (tests / benchmarks only) makes it reproducible
+        and is NOT a source of key material."""
         out = (u64 * 5)()
-        lib().p2_ecgfp5_random_scalar(seed, out)
+        if seed is None:
+            if lib().p2_ecgfp5_random_scalar(out):
+                raise P2Error(_err())
+        else:
+            lib().p2_ecgfp5_random_scalar_seeded(seed, out)
         return sum(int(out[i]) << (64 * i) for i in range(5))
 
     @staticmethod
-    def new_rand_from_subgroup(seed):
+    def new_rand_from_subgroup(seed=None):
         out = (u64 * 10)()
-        lib().p2_ecgfp5_random_point(seed, out)
+        if seed is None:
+            if lib().p2_ecgfp5_random_point(out):
+                raise P2Error(_err())
+        else:
+            lib().p2_ecgfp5_random_point_seeded(seed, out)
         return _pt_out(out)
 
     @staticmethod
-    def encode_binary(x, seed):                            # lib.rs:48
+    def encode_binary(x, seed=None):                       # lib.rs:48
         assert 0 <= x < 1 << 160
         out = (u64 * 10)()
-        lib().p2_ecgfp5_encode_binary((C.c_uint32 * 5)(*[(x >> (32 * i)) & 0xFFFFFFFF for i in range(5)]), seed, out)
+        limbs = (C.c_uint32 * 5)(*[(x >> (32 * i)) & 0xFFFFFFFF for i in range(5)])
+        if seed is None:
+            if lib().p2_ecgfp5_encode_binary(limbs, out):
+                raise P2Error(_err())
+        else:
+            lib().p2_ecgfp5_encode_binary_seeded(limbs, seed, out)
         return _pt_out(out)
 
     @staticmethod
@@ -649,7 +686,7 @@ class ECGFP5SecretKey:
         self.value = s
 
     @staticmethod
-    def rand(seed): return ECGFP5SecretKey(ecgfp5.random_scalar(seed))
+    def rand(seed=None): return ECGFP5SecretKey(ecgfp5.random_scalar(seed))   # lib.rs:35 OsRng; seed = tests only
 
     def public_key(self): return ecgfp5.mul(self.value, ecgfp5.generator())
 

@@ -53,5 +53,7 @@ inline void fill_info(const Circuit& c, p2_circuit_info* o) {
     o->num_virtual_targets = (uint32_t)c.vt_slot.size();
     o->num_fri_rounds = (uint32_t)c.reduction_arity_bits().size();
     o->proof_bytes = proof_bytes(c);
+    o->zero_knowledge = c.cfg.zero_knowledge;
+    o->num_gate_kinds = (uint32_t)c.gates.size();
 }
 }  // namespace p2

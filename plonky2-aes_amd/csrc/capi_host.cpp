@@ -20,6 +20,34 @@ struct p2_builder {
     CircuitBuilder b;
 };
 
+
+// No exception may cross the C boundary: every entry point that runs builder / gadget code goes through one of these.
+// The message lands in p2_last_error(); the return value is the function's error value (an error code, UINT64_MAX for a
+// target, (size_t)-1 for an index; a void function leaves its outputs untouched).
+template <class F>
+static int guarded(F f) {
+    try {
+        f();
+        return P2_OK;
+    } catch (std::exception& e) {
+        return set_error(e.what()), P2_ERR_INVALID;
+    } catch (...) {
+        return set_error("unknown C++ exception"), P2_ERR_INVALID;
+    }
+}
+template <class F>
+static p2_target guarded_t(F f) {
+    p2_target r = UINT64_MAX;
+    (void)guarded([&] { r = f(); });
+    return r;
+}
+template <class F>
+static size_t guarded_sz(F f) {
+    size_t r = (size_t)-1;
+    (void)guarded([&] { r = f(); });
+    return r;
+}
+
 extern "C" {
 
 const char* p2_last_error(void) { return p2::g_last_error.c_str(); }
@@ -31,24 +59,24 @@ p2_builder* p2_builder_new_zk(void) {
     return new p2_builder{CircuitBuilder(cfg)};
 }
 void p2_builder_free(p2_builder* b) { delete b; }
-p2_target p2_builder_add_virtual_target(p2_builder* b) { return b->b.add_virtual_target(); }
-p2_target p2_builder_constant(p2_builder* b, uint64_t c) { return b->b.constant(c); }
-p2_target p2_builder_zero(p2_builder* b) { return b->b.zero(); }
-p2_target p2_builder_one(p2_builder* b) { return b->b.one(); }
-p2_target p2_builder_arithmetic(p2_builder* b, uint64_t c0, uint64_t c1, p2_target m0, p2_target m1, p2_target a) {
-    return b->b.arithmetic(c0 % gl::P, c1 % gl::P, m0, m1, a);
-}
-p2_target p2_builder_mul_const_add(p2_builder* b, uint64_t c, p2_target x, p2_target y) { return b->b.mul_const_add(c % gl::P, x, y); }
-p2_target p2_builder_add(p2_builder* b, p2_target x, p2_target y) { return b->b.add(x, y); }
-p2_target p2_builder_sub(p2_builder* b, p2_target x, p2_target y) { return b->b.sub(x, y); }
-p2_target p2_builder_mul(p2_builder* b, p2_target x, p2_target y) { return b->b.mul(x, y); }
-p2_target p2_builder_select(p2_builder* b, p2_target c, p2_target x, p2_target y) { return b->b.select(BoolTarget{c}, x, y); }
-p2_target p2_builder_is_equal(p2_builder* b, p2_target x, p2_target y) { return b->b.is_equal(x, y).target; }
-void p2_builder_connect(p2_builder* b, p2_target x, p2_target y) { b->b.connect(x, y); }
+p2_target p2_builder_add_virtual_target(p2_builder* b) { return guarded_t([&]() -> p2_target { return b->b.add_virtual_target(); }); }
+p2_target p2_builder_constant(p2_builder* b, uint64_t c) { return guarded_t([&]() -> p2_target { return b->b.constant(c); }); }
+p2_target p2_builder_zero(p2_builder* b) { return guarded_t([&]() -> p2_target { return b->b.zero(); }); }
+p2_target p2_builder_one(p2_builder* b) { return guarded_t([&]() -> p2_target { return b->b.one(); }); }
+p2_target p2_builder_arithmetic(p2_builder* b, uint64_t c0, uint64_t c1, p2_target m0, p2_target m1, p2_target a) { return guarded_t([&]() -> p2_target {    return b->b.arithmetic(c0 % gl::P, c1 % gl::P, m0, m1, a);}); }
+p2_target p2_builder_mul_const_add(p2_builder* b, uint64_t c, p2_target x, p2_target y) { return guarded_t([&]() -> p2_target { return b->b.mul_const_add(c % gl::P, x, y); }); }
+p2_target p2_builder_add(p2_builder* b, p2_target x, p2_target y) { return guarded_t([&]() -> p2_target { return b->b.add(x, y); }); }
+p2_target p2_builder_sub(p2_builder* b, p2_target x, p2_target y) { return guarded_t([&]() -> p2_target { return b->b.sub(x, y); }); }
+p2_target p2_builder_mul(p2_builder* b, p2_target x, p2_target y) { return guarded_t([&]() -> p2_target { return b->b.mul(x, y); }); }
+p2_target p2_builder_select(p2_builder* b, p2_target c, p2_target x, p2_target y) { return guarded_t([&]() -> p2_target { return b->b.select(BoolTarget{c}, x, y); }); }
+p2_target p2_builder_is_equal(p2_builder* b, p2_target x, p2_target y) { return guarded_t([&]() -> p2_target { return b->b.is_equal(x, y).target; }); }
+void p2_builder_connect(p2_builder* b, p2_target x, p2_target y) { (void)guarded([&] { b->b.connect(x, y); }); }
 size_t p2_builder_add_lookup_table_from_pairs(p2_builder* b, const uint16_t* pairs, size_t n) {
-    std::vector<std::pair<u16, u16>> t(n);
-    for (size_t i = 0; i < n; i++) t[i] = {pairs[2 * i], pairs[2 * i + 1]};
-    return b->b.add_lookup_table_from_pairs(t);
+    return guarded_sz([&]() -> size_t {
+        std::vector<std::pair<u16, u16>> t(n);
+        for (size_t i = 0; i < n; i++) t[i] = {pairs[2 * i], pairs[2 * i + 1]};
+        return b->b.add_lookup_table_from_pairs(t);
+    });
 }
 p2_target p2_builder_add_lookup_from_index(p2_builder* b, p2_target in, size_t lut) {
     try {
@@ -58,7 +86,7 @@ p2_target p2_builder_add_lookup_from_index(p2_builder* b, p2_target in, size_t l
         return UINT64_MAX;
     }
 }
-size_t p2_builder_num_gates(const p2_builder* b) { return b->b.num_gates(); }
+size_t p2_builder_num_gates(const p2_builder* b) { return guarded_sz([&]() -> size_t { return b->b.num_gates(); }); }
 int p2_builder_build(p2_builder* b, uint8_t** blob, size_t* len) {
     try {
         Circuit c = b->b.build();
@@ -97,11 +125,11 @@ static aes::BlockTarget block_in(const p2_target* b) {
     for (int i = 0; i < 16; i++) r[i] = b[i];
     return r;
 }
-size_t p2_aes_sbox_lut(p2_builder* b) { return aes::sbox_lut(b->b); }
-size_t p2_aes_byte_xor_lut(p2_builder* b) { return aes::byte_xor_lut(b->b); }
-size_t p2_aes_gf_2_8_mul_lut(p2_builder* b) { return aes::gf_2_8_mul_lut(b->b); }
-size_t p2_gcm_u8_unit_right_shift_lut(p2_builder* b) { return aes::u8_unit_right_shift_lut(b->b); }
-size_t p2_gcm_u8_bitref_lut(p2_builder* b) { return aes::u8_bitref_lut(b->b); }
+size_t p2_aes_sbox_lut(p2_builder* b) { return guarded_sz([&]() -> size_t { return aes::sbox_lut(b->b); }); }
+size_t p2_aes_byte_xor_lut(p2_builder* b) { return guarded_sz([&]() -> size_t { return aes::byte_xor_lut(b->b); }); }
+size_t p2_aes_gf_2_8_mul_lut(p2_builder* b) { return guarded_sz([&]() -> size_t { return aes::gf_2_8_mul_lut(b->b); }); }
+size_t p2_gcm_u8_unit_right_shift_lut(p2_builder* b) { return guarded_sz([&]() -> size_t { return aes::u8_unit_right_shift_lut(b->b); }); }
+size_t p2_gcm_u8_bitref_lut(p2_builder* b) { return guarded_sz([&]() -> size_t { return aes::u8_bitref_lut(b->b); }); }
 p2_target p2_aes_add_virtual_byte_target(p2_builder* b, size_t t) {
     try {
         return aes::add_virtual_byte_target(b->b, t);
@@ -110,41 +138,55 @@ p2_target p2_aes_add_virtual_byte_target(p2_builder* b, size_t t) {
         return UINT64_MAX;
     }
 }
-p2_target p2_aes_add_virtual_byte_target_unsafe(p2_builder* b) { return aes::add_virtual_byte_target_unsafe(b->b); }
-void p2_aes_state_sub_bytes(p2_builder* b, size_t sbox, const p2_target* s, p2_target* out) { state_out(aes::state_sub_bytes(b->b, sbox, state_in(s)), out); }
+p2_target p2_aes_add_virtual_byte_target_unsafe(p2_builder* b) { return guarded_t([&]() -> p2_target { return aes::add_virtual_byte_target_unsafe(b->b); }); }
+void p2_aes_state_sub_bytes(p2_builder* b, size_t sbox, const p2_target* s, p2_target* out) { (void)guarded([&] { state_out(aes::state_sub_bytes(b->b, sbox, state_in(s)), out); }); }
 void p2_aes_state_mix_columns(p2_builder* b, size_t xl, size_t ml, const p2_target* s, p2_target* out) {
-    aes::StateTarget mix = aes::state_mix_matrix(b->b);
-    state_out(aes::state_mix_columns(b->b, xl, ml, mix, state_in(s)), out);
+    (void)guarded([&] {
+        aes::StateTarget mix = aes::state_mix_matrix(b->b);
+        state_out(aes::state_mix_columns(b->b, xl, ml, mix, state_in(s)), out);
+    });
 }
-p2_target p2_aes_gf_2_8_mul(p2_builder* b, size_t ml, p2_target x, p2_target y) { return aes::gf_2_8_mul_t(b->b, ml, x, y); }
-p2_target p2_aes_gf_2_8_add(p2_builder* b, size_t xl, p2_target x, p2_target y) { return aes::gf_2_8_add(b->b, xl, x, y); }
+p2_target p2_aes_gf_2_8_mul(p2_builder* b, size_t ml, p2_target x, p2_target y) { return guarded_t([&]() -> p2_target { return aes::gf_2_8_mul_t(b->b, ml, x, y); }); }
+p2_target p2_aes_gf_2_8_add(p2_builder* b, size_t xl, p2_target x, p2_target y) { return guarded_t([&]() -> p2_target { return aes::gf_2_8_add(b->b, xl, x, y); }); }
 void p2_aes_key_expansion(p2_builder* b, int nk, int nr, size_t xl, size_t sl, const p2_target* key, p2_target* out) {
-    std::vector<aes::ByteTarget> k(key, key + 4 * nk);
-    auto w = aes::key_expansion_t(b->b, nk, nr, xl, sl, k);
-    for (size_t i = 0; i < w.size(); i++)
-        for (int j = 0; j < 4; j++) out[4 * i + j] = w[i][j];
+    (void)guarded([&] {
+        std::vector<aes::ByteTarget> k(key, key + 4 * nk);
+        auto w = aes::key_expansion_t(b->b, nk, nr, xl, sl, k);
+        for (size_t i = 0; i < w.size(); i++)
+            for (int j = 0; j < 4; j++) out[4 * i + j] = w[i][j];
+    });
 }
 void p2_aes_encrypt_block(p2_builder* b, int nr, size_t xl, size_t ml, size_t sl, const p2_target* state, const p2_target* ek, p2_target* out) {
-    aes::StateTarget mix = aes::state_mix_matrix(b->b);
-    state_out(aes::encrypt_block_t(b->b, nr, xl, ml, sl, mix, state_in(state), words_in(ek, 4 * (nr + 1))), out);
+    (void)guarded([&] {
+        aes::StateTarget mix = aes::state_mix_matrix(b->b);
+        state_out(aes::encrypt_block_t(b->b, nr, xl, ml, sl, mix, state_in(state), words_in(ek, 4 * (nr + 1))), out);
+    });
 }
 void p2_gcm_gctr(p2_builder* b, int nr, size_t xl, size_t ml, size_t sl, const p2_target* ek, const p2_target* icb, const p2_target* x, size_t len, p2_target* y) {
-    aes::StateTarget mix = aes::state_mix_matrix(b->b);
-    std::vector<aes::ByteTarget> xv(x, x + len);
-    auto r = aes::gctr_target(b->b, nr, xl, ml, sl, mix, words_in(ek, 4 * (nr + 1)), block_in(icb), xv);
-    for (size_t i = 0; i < len; i++) y[i] = r[i];
+    (void)guarded([&] {
+        aes::StateTarget mix = aes::state_mix_matrix(b->b);
+        std::vector<aes::ByteTarget> xv(x, x + len);
+        auto r = aes::gctr_target(b->b, nr, xl, ml, sl, mix, words_in(ek, 4 * (nr + 1)), block_in(icb), xv);
+        for (size_t i = 0; i < len; i++) y[i] = r[i];
+    });
 }
 void p2_gcm_right_shift_one(p2_builder* b, size_t shl, const p2_target* v, p2_target* out) {
-    auto r = aes::right_shift_one_target(b->b, shl, block_in(v));
-    for (int i = 0; i < 16; i++) out[i] = r[i];
+    (void)guarded([&] {
+        auto r = aes::right_shift_one_target(b->b, shl, block_in(v));
+        for (int i = 0; i < 16; i++) out[i] = r[i];
+    });
 }
 void p2_gcm_inc32(p2_builder* b, const p2_target* blk, p2_target* out) {
-    auto r = aes::inc32_target(b->b, block_in(blk));
-    for (int i = 0; i < 16; i++) out[i] = r[i];
+    (void)guarded([&] {
+        auto r = aes::inc32_target(b->b, block_in(blk));
+        for (int i = 0; i < 16; i++) out[i] = r[i];
+    });
 }
 void p2_gcm_gf_2_128_mul(p2_builder* b, size_t xl, size_t shl, size_t brl, const p2_target* x, const p2_target* y, p2_target* out) {
-    auto r = aes::gf_2_128_mul_target(b->b, xl, shl, brl, block_in(x), block_in(y));
-    for (int i = 0; i < 16; i++) out[i] = r[i];
+    (void)guarded([&] {
+        auto r = aes::gf_2_128_mul_target(b->b, xl, shl, brl, block_in(x), block_in(y));
+        for (int i = 0; i < 16; i++) out[i] = r[i];
+    });
 }
 int p2_gcm_ghash(p2_builder* b, size_t xl, size_t shl, size_t brl, const p2_target* h, const p2_target* x, size_t len, p2_target* out) {
     try {
@@ -200,15 +242,19 @@ int p2_poseidon_cipher_build(p2_builder* b, size_t L, p2_target* ks, p2_target* 
     }
 }
 void p2_native_hash_n_to_m_no_pad(const uint64_t* in, size_t n, uint64_t* out, size_t m) {
-    auto o = pcipher::hash_n_to_m_no_pad(std::vector<u64>(in, in + n), m);
-    std::copy(o.begin(), o.end(), out);
+    (void)guarded([&] {
+        auto o = pcipher::hash_n_to_m_no_pad(std::vector<u64>(in, in + n), m);
+        std::copy(o.begin(), o.end(), out);
+    });
 }
 static pcipher::Fq fq_at(const uint64_t* p) { return pcipher::Fq{p[0], p[1], p[2], p[3], p[4]}; }
 void p2_native_poseidon_encrypt(const uint64_t* ks, const uint64_t* msg, size_t n_msg, const uint64_t* nonce, uint64_t* ct) {
-    std::vector<pcipher::Fq> m(n_msg);
-    for (size_t i = 0; i < n_msg; i++) m[i] = fq_at(msg + 5 * i);
-    auto c = pcipher::encrypt(fq_at(ks), fq_at(ks + 5), m, nonce);
-    for (size_t i = 0; i < c.size(); i++) memcpy(ct + 5 * i, c[i].data(), 40);
+    (void)guarded([&] {
+        std::vector<pcipher::Fq> m(n_msg);
+        for (size_t i = 0; i < n_msg; i++) m[i] = fq_at(msg + 5 * i);
+        auto c = pcipher::encrypt(fq_at(ks), fq_at(ks + 5), m, nonce);
+        for (size_t i = 0; i < c.size(); i++) memcpy(ct + 5 * i, c[i].data(), 40);
+    });
 }
 int p2_native_poseidon_decrypt(const uint64_t* ks, const uint64_t* ct, size_t n_ct, const uint64_t* nonce, size_t l, uint64_t* msg) {
     std::vector<pcipher::Fq> c(n_ct), m;
@@ -246,32 +292,56 @@ static int scalar_ok(const uint64_t* k) {
     if (!ecgfp5::u320_lt(sc_at(k), ecgfp5::GROUP_ORDER)) return set_error("scalar is not below the group order"), P2_ERR_INVALID;
     return P2_OK;
 }
-void p2_ecgfp5_group_order(uint64_t out[5]) { memcpy(out, ecgfp5::GROUP_ORDER.w, 40); }
-void p2_ecgfp5_generator(uint64_t out[10]) { pt_put(ecgfp5::generator(), out); }
-void p2_ecgfp5_mul(const uint64_t k[5], const uint64_t p[10], uint64_t out[10]) { pt_put(ecgfp5::scalar_mul(sc_at(k), pt_at(p)), out); }
-void p2_ecgfp5_add(const uint64_t p[10], const uint64_t q[10], uint64_t out[10]) { pt_put(ecgfp5::point_add(pt_at(p), pt_at(q)), out); }
-void p2_ecgfp5_neg(const uint64_t p[10], uint64_t out[10]) { pt_put(ecgfp5::point_neg(pt_at(p)), out); }
+void p2_ecgfp5_group_order(uint64_t out[5]) { (void)guarded([&] { memcpy(out, ecgfp5::GROUP_ORDER.w, 40); }); }
+void p2_ecgfp5_generator(uint64_t out[10]) { (void)guarded([&] { pt_put(ecgfp5::generator(), out); }); }
+void p2_ecgfp5_mul(const uint64_t k[5], const uint64_t p[10], uint64_t out[10]) { (void)guarded([&] { pt_put(ecgfp5::scalar_mul(sc_at(k), pt_at(p)), out); }); }
+void p2_ecgfp5_add(const uint64_t p[10], const uint64_t q[10], uint64_t out[10]) { (void)guarded([&] { pt_put(ecgfp5::point_add(pt_at(p), pt_at(q)), out); }); }
+void p2_ecgfp5_neg(const uint64_t p[10], uint64_t out[10]) { (void)guarded([&] { pt_put(ecgfp5::point_neg(pt_at(p)), out); }); }
 int p2_ecgfp5_is_in_subgroup(const uint64_t p[10]) { return ecgfp5::is_in_subgroup(pt_at(p)) ? 1 : 0; }
-void p2_ecgfp5_compress(const uint64_t p[10], uint64_t w[5]) { memcpy(w, ecgfp5::compress_from_subgroup(pt_at(p)).data(), 40); }
+void p2_ecgfp5_compress(const uint64_t p[10], uint64_t w[5]) { (void)guarded([&] { memcpy(w, ecgfp5::compress_from_subgroup(pt_at(p)).data(), 40); }); }
 int p2_ecgfp5_decompress(const uint64_t w[5], uint64_t out[10]) {
     ecgfp5::Affine a;
     if (!ecgfp5::decompress_into_subgroup(fq_at(w), &a)) return set_error("not the encoding of a group element"), P2_ERR_INVALID;
     pt_put(a, out);
     return P2_OK;
 }
-void p2_ecgfp5_random_scalar(uint64_t seed, uint64_t out[5]) {
-    ecgfp5::SplitMix rng{seed};
-    memcpy(out, ecgfp5::random_scalar(rng).w, 40);
+int p2_ecgfp5_random_scalar(uint64_t out[5]) {
+    return guarded([&] {
+        ecgfp5::Rng rng = ecgfp5::Rng::os();
+        memcpy(out, ecgfp5::random_scalar(rng).w, 40);
+    });
 }
-void p2_ecgfp5_random_point(uint64_t seed, uint64_t out[10]) {
-    ecgfp5::SplitMix rng{seed};
-    pt_put(ecgfp5::random_point(rng), out);
+int p2_ecgfp5_random_point(uint64_t out[10]) {
+    return guarded([&] {
+        ecgfp5::Rng rng = ecgfp5::Rng::os();
+        pt_put(ecgfp5::random_point(rng), out);
+    });
 }
-void p2_ecgfp5_encode_binary(const uint32_t limbs[5], uint64_t seed, uint64_t out[10]) {
-    ecgfp5::SplitMix rng{seed};
-    pt_put(ecgfp5::encode_binary(limbs, rng), out);
+int p2_ecgfp5_encode_binary(const uint32_t limbs[5], uint64_t out[10]) {
+    return guarded([&] {
+        ecgfp5::Rng rng = ecgfp5::Rng::os();
+        pt_put(ecgfp5::encode_binary(limbs, rng), out);
+    });
 }
-void p2_ecgfp5_decode_binary(const uint64_t p[10], uint32_t limbs[5]) { ecgfp5::decode_binary(pt_at(p), limbs); }
+void p2_ecgfp5_random_scalar_seeded(uint64_t seed, uint64_t out[5]) {
+    (void)guarded([&] {
+        ecgfp5::Rng rng = ecgfp5::Rng::from_seed(seed);
+        memcpy(out, ecgfp5::random_scalar(rng).w, 40);
+    });
+}
+void p2_ecgfp5_random_point_seeded(uint64_t seed, uint64_t out[10]) {
+    (void)guarded([&] {
+        ecgfp5::Rng rng = ecgfp5::Rng::from_seed(seed);
+        pt_put(ecgfp5::random_point(rng), out);
+    });
+}
+void p2_ecgfp5_encode_binary_seeded(const uint32_t limbs[5], uint64_t seed, uint64_t out[10]) {
+    (void)guarded([&] {
+        ecgfp5::Rng rng = ecgfp5::Rng::from_seed(seed);
+        pt_put(ecgfp5::encode_binary(limbs, rng), out);
+    });
+}
+void p2_ecgfp5_decode_binary(const uint64_t p[10], uint32_t limbs[5]) { (void)guarded([&] { ecgfp5::decode_binary(pt_at(p), limbs); }); }
 int p2_elgamal_encrypt(const uint64_t pk[10], const uint64_t nonce[5], const uint64_t msg[10], uint64_t c0[10], uint64_t c1[10]) {
     if (scalar_ok(nonce)) return P2_ERR_INVALID;
     ecgfp5::Affine a, b;
@@ -297,11 +367,13 @@ int p2_hashed_elgamal_decrypt(const uint64_t sk[5], const uint64_t c0[10], const
     ecgfp5::hashed_elgamal_decrypt(sc_at(sk), pt_at(c0), ct, msg);
     return P2_OK;
 }
-void p2_builder_add_virtual_point_target(p2_builder* b, p2_target out[10]) { ptt_put(ecgfp5::add_virtual_point_target(b->b), out); }
-void p2_builder_constant_point(p2_builder* b, const uint64_t p[10], p2_target out[10]) { ptt_put(ecgfp5::constant_point(b->b, pt_at(p)), out); }
+void p2_builder_add_virtual_point_target(p2_builder* b, p2_target out[10]) { (void)guarded([&] { ptt_put(ecgfp5::add_virtual_point_target(b->b), out); }); }
+void p2_builder_constant_point(p2_builder* b, const uint64_t p[10], p2_target out[10]) { (void)guarded([&] { ptt_put(ecgfp5::constant_point(b->b, pt_at(p)), out); }); }
 void p2_builder_add_virtual_biguint320_target(p2_builder* b, p2_target bits[320]) {
-    auto v = ecgfp5::add_virtual_biguint320_target(b->b);
-    for (size_t i = 0; i < v.size(); i++) bits[i] = v[i].target;
+    (void)guarded([&] {
+        auto v = ecgfp5::add_virtual_biguint320_target(b->b);
+        for (size_t i = 0; i < v.size(); i++) bits[i] = v[i].target;
+    });
 }
 int p2_builder_multiply_point(p2_builder* b, const p2_target bits[320], const p2_target p[10], p2_target out[10]) {
     try {
@@ -311,9 +383,7 @@ int p2_builder_multiply_point(p2_builder* b, const p2_target bits[320], const p2
         return set_error(e.what()), P2_ERR_INVALID;
     }
 }
-void p2_builder_add_point(p2_builder* b, const p2_target p[10], const p2_target q[10], p2_target out[10]) {
-    ptt_put(ecgfp5::add_point(b->b, ptt_at(p), ptt_at(q)), out);
-}
+void p2_builder_add_point(p2_builder* b, const p2_target p[10], const p2_target q[10], p2_target out[10]) { (void)guarded([&] {    ptt_put(ecgfp5::add_point(b->b, ptt_at(p), ptt_at(q)), out);}); }
 int p2_builder_public_key(p2_builder* b, const p2_target sk_bits[320], p2_target pk[10]) {
     try {
         ptt_put(ecgfp5::public_key_target(b->b, bits_at(sk_bits)), pk);
@@ -394,30 +464,38 @@ int p2_selftest_host(uint64_t seed, size_t n_reductions, size_t n_permutations) 
 // ---- native cipher
 uint8_t p2_native_gf_2_8_mul(uint8_t a, uint8_t b) { return aes::gf_2_8_mul(a, b); }
 void p2_native_aes_key_expansion(const uint8_t* key, int nk, int nr, uint8_t* out) {
-    auto w = aes::key_expansion(nk, nr, key);
-    for (size_t i = 0; i < w.size(); i++) memcpy(out + 4 * i, w[i].data(), 4);
+    (void)guarded([&] {
+        auto w = aes::key_expansion(nk, nr, key);
+        for (size_t i = 0; i < w.size(); i++) memcpy(out + 4 * i, w[i].data(), 4);
+    });
 }
 void p2_native_aes_encrypt_block(const uint8_t* key, int nk, int nr, const uint8_t* in, uint8_t* out) {
-    auto w = aes::key_expansion(nk, nr, key);
-    auto s = aes::flatten_state(aes::encrypt_block(nr, in, w));
-    memcpy(out, s.data(), 16);
+    (void)guarded([&] {
+        auto w = aes::key_expansion(nk, nr, key);
+        auto s = aes::flatten_state(aes::encrypt_block(nr, in, w));
+        memcpy(out, s.data(), 16);
+    });
 }
 void p2_native_gf_2_128_mul(const uint8_t* x, const uint8_t* y, uint8_t* out) {
-    auto r = aes::gf_2_128_mul(x, y);
-    memcpy(out, r.data(), 16);
+    (void)guarded([&] {
+        auto r = aes::gf_2_128_mul(x, y);
+        memcpy(out, r.data(), 16);
+    });
 }
 void p2_native_ghash(const uint8_t* h, const uint8_t* x, size_t len, uint8_t* out) {
-    auto r = aes::ghash(h, x, len);
-    memcpy(out, r.data(), 16);
+    (void)guarded([&] {
+        auto r = aes::ghash(h, x, len);
+        memcpy(out, r.data(), 16);
+    });
 }
 void p2_native_gctr(const uint8_t* key, int nk, int nr, const uint8_t* icb, const uint8_t* x, size_t len, uint8_t* y) {
-    auto w = aes::key_expansion(nk, nr, key);
-    auto r = aes::gctr(nr, w, icb, x, len);
-    if (len) memcpy(y, r.data(), len);
+    (void)guarded([&] {
+        auto w = aes::key_expansion(nk, nr, key);
+        auto r = aes::gctr(nr, w, icb, x, len);
+        if (len) memcpy(y, r.data(), len);
+    });
 }
-void p2_native_aes_gcm_encrypt(const uint8_t* key, int nk, int nr, const uint8_t* nonce, const uint8_t* pt, size_t len, uint8_t* ct, uint8_t* tag) {
-    aes::gcm_encrypt(nk, nr, key, nonce, pt, len, ct, tag);
-}
+void p2_native_aes_gcm_encrypt(const uint8_t* key, int nk, int nr, const uint8_t* nonce, const uint8_t* pt, size_t len, uint8_t* ct, uint8_t* tag) { (void)guarded([&] {    aes::gcm_encrypt(nk, nr, key, nonce, pt, len, ct, tag);}); }
 
 // ---- info / verify
 int p2_blob_info(const uint8_t* blob, size_t len, p2_circuit_info* out) {

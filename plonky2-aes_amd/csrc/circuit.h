@@ -39,26 +39,19 @@ struct Config {
 };
 static const u32 SALT_SIZE = 4;  // plonky2 fri::oracle SALT_SIZE: random elements appended to every leaf of a blinded oracle
 
-// Blinding randomness.  Upstream draws from the OS RNG (proofs are not reproducible); here every random element is a
-// keyed function of (seed, proof index, domain, index) so that the GPU prover and the CPU oracle produce identical
-// proofs.  SplitMix64 finaliser, reduced mod p (bias 2^-32, irrelevant for blinding).
+// Blinding randomness.  Upstream draws every blinding element from the OS RNG.  Here the handle holds a 256-bit key
+// (four field elements, drawn from the OS CSPRNG at p2_circuit_load) and every element is the output of a PRF:
+//     zk_block(key, proof, domain, block) = Poseidon(key[0..4] | proof | domain | block | ZK_TAG | 0^4)[0..8]
+//     element `index` of (proof, domain)  = zk_block(key, proof, domain, index >> 3)[index & 7]
+// (an outer-keyed sponge squeezing its rate; the four capacity words stay hidden, so published salts do not reveal the
+// key).  `proof` is a per-handle counter that advances with every proof attempted, so no (key, proof) pair is ever
+// reused.  With p2_circuit_set_zk_key the key is fixed and proofs are reproducible: that is what lets the CPU oracle
+// (its own restatement in oracle/oracle_prover.h) check zk proofs byte for byte.  Evaluated in zk_prf.h.
 enum ZkDomain : u64 { ZK_ROW = 1, ZK_ZROW = 2, ZK_SALT = 3 /* + oracle index */ };
-#if defined(__HIPCC__)
-__host__ __device__
-#endif
-static inline u64 zk_rand(u64 seed, u64 proof, u64 domain, u64 index) {
-    u64 x = seed ^ (proof * 0x9E3779B97F4A7C15ull) ^ (domain << 56);
-    for (int round = 0; round < 2; round++) {
-        x += 0x9E3779B97F4A7C15ull + (round ? index : 0);
-        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-        x ^= x >> 31;
-        x ^= index * 0xD6E8FEB86659FD93ull;
-    }
-    x = (x ^ (x >> 32)) * 0xD6E8FEB86659FD93ull;
-    x ^= x >> 29;
-    return x % 0xFFFFFFFF00000001ull;
-}
+static const u64 ZK_TAG = 0x7a6b5f626c696e64ull;  // "zk_blind"
+struct ZkKey {
+    u64 k[4];
+};
 
 // Gate kinds in plonky2's sort order (degree, id) for the gates the gadget crates instantiate.
 enum GateKind : u32 {

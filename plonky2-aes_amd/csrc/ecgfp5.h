@@ -14,6 +14,7 @@
 #include <array>
 
 #include "builder.h"
+#include "os_random.h"
 #include "poseidon_cipher.h"
 
 namespace p2 {
@@ -126,9 +127,20 @@ inline bool u320_lt(const U320& a, const U320& b) {
         if (a.w[i] != b.w[i]) return a.w[i] < b.w[i];
     return false;
 }
-struct SplitMix {
+// Randomness for keys, nonces and encode_binary padding.  The default source is the operating system's CSPRNG, as in the
+// reference (OsRng: ecgfp5/src/lib.rs:35,64; poseidon-cipher/src/lib.rs:32,37).  The seeded form (SplitMix64) exists for
+// tests and benchmarks that need reproducible inputs: 64 bits of a non-cryptographic generator, never a real key.
+struct Rng {
+    bool seeded;
     u64 s;
+    static Rng os() { return Rng{false, 0}; }
+    static Rng from_seed(u64 seed) { return Rng{true, seed}; }
     u64 next() {
+        if (!seeded) {
+            u64 v;
+            os_random_bytes(&v, 8);
+            return v;
+        }
         u64 z = (s += 0x9E3779B97F4A7C15ull);
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -141,8 +153,8 @@ struct SplitMix {
         }
     }
 };
-// gen_biguint_below(&GROUP_ORDER) with a caller-supplied seed (upstream: OsRng)
-inline U320 random_scalar(SplitMix& rng) {
+// gen_biguint_below(&GROUP_ORDER): rejection sampling of 319-bit values
+inline U320 random_scalar(Rng& rng) {
     for (;;) {
         U320 k;
         for (int i = 0; i < 5; i++) k.w[i] = rng.next();
@@ -220,7 +232,7 @@ inline Affine scalar_mul(const U320& k, const Affine& p) { return Point::from_af
 inline Affine point_add(const Affine& p, const Affine& q) { return Point::from_affine(p).add(Point::from_affine(q)).affine(); }
 inline Affine point_neg(const Affine& p) { return Affine{p.x, fq_neg(p.u)}; }
 inline Affine public_key(const U320& sk) { return scalar_mul(sk, generator()); }                  // lib.rs:39
-inline Affine random_point(SplitMix& rng) { return scalar_mul(random_scalar(rng), generator()); }  // new_rand_from_subgroup, UNPINNED
+inline Affine random_point(Rng& rng) { return scalar_mul(random_scalar(rng), generator()); }  // new_rand_from_subgroup, UNPINNED
 inline std::vector<u64> as_fields(const Affine& a) {
     std::vector<u64> f(a.x.begin(), a.x.end());
     f.insert(f.end(), a.u.begin(), a.u.end());
@@ -228,7 +240,7 @@ inline std::vector<u64> as_fields(const Affine& a) {
 }
 
 // lib.rs:48  160 message bits, 32 in the low half of every limb, the high halves random until the element decodes
-inline Affine encode_binary(const u32 limbs[5], SplitMix& rng) {
+inline Affine encode_binary(const u32 limbs[5], Rng& rng) {
     for (;;) {
         Fq w;
         for (int i = 0; i < 5; i++) {

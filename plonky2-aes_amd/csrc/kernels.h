@@ -13,6 +13,7 @@
 #include "gl.h"
 #include "poseidon_fast.h"
 #include "poseidon_gate.h"
+#include "zk_prf.h"
 
 namespace p2k {
 using gl::E2;
@@ -494,29 +495,44 @@ __global__ void k_fill_advice(const int32_t* __restrict__ pos_index /*[n]: advic
 }
 
 // zk blinding rows: every wire of a `rows` entry is random; the 80 routed wires of both rows of a `zrows` pair carry the
-// same random value (they are copy-constrained)
+// same random value (they are copy-constrained).  One thread = one PRF block of eight elements.
 __global__ void k_fill_blind(const u32* __restrict__ rows, u32 n_rows, const u32* __restrict__ zrows, u32 n_z, u64* __restrict__ wires,
-                             size_t wires_batch_stride, u32 n, u64 seed, u64 proof_base) {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+                             size_t wires_batch_stride, u32 n, p2::ZkKey key, u64 proof_base) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     u64* w = wires + (size_t)blockIdx.y * wires_batch_stride;
     const u64 proof = proof_base + blockIdx.y;
-    const size_t regular = (size_t)n_rows * 135;
-    if (idx < regular) {
-        u32 k = (u32)(idx / 135), c = (u32)(idx % 135);
-        w[(size_t)c * n + rows[k]] = p2::zk_rand(seed, proof, p2::ZK_ROW, idx);
-    } else if (idx < regular + (size_t)n_z * 80) {
-        size_t j = idx - regular;
-        u32 k = (u32)(j / 80), c = (u32)(j % 80);
-        u64 v = p2::zk_rand(seed, proof, p2::ZK_ZROW, j);
-        w[(size_t)c * n + zrows[2 * k]] = v;
-        w[(size_t)c * n + zrows[2 * k + 1]] = v;
+    const size_t regular = (size_t)n_rows * 135, nb_reg = (regular + 7) / 8, zcount = (size_t)n_z * 80, nb_z = (zcount + 7) / 8;
+    u64 v[8];
+    if (t < nb_reg) {
+        p2::zk_block(key, proof, p2::ZK_ROW, t, v);
+        for (int j = 0; j < 8; j++) {
+            size_t idx = 8 * t + j;
+            if (idx < regular) w[(size_t)(idx % 135) * n + rows[idx / 135]] = v[j];
+        }
+    } else if (t < nb_reg + nb_z) {
+        t -= nb_reg;
+        p2::zk_block(key, proof, p2::ZK_ZROW, t, v);
+        for (int j = 0; j < 8; j++) {
+            size_t idx = 8 * t + j;
+            if (idx < zcount) {
+                u32 k = (u32)(idx / 80), c = (u32)(idx % 80);
+                w[(size_t)c * n + zrows[2 * k]] = v[j];
+                w[(size_t)c * n + zrows[2 * k + 1]] = v[j];
+            }
+        }
     }
 }
-// SALT_SIZE random columns appended to a blinded oracle's LDE matrix (they are leaf data only, not polynomials)
-__global__ void k_fill_salt(u64* __restrict__ salt_cols, size_t batch_stride, size_t N, u64 seed, u64 proof_base, u64 domain) {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= p2::SALT_SIZE * N) return;
-    salt_cols[(size_t)blockIdx.y * batch_stride + idx] = p2::zk_rand(seed, proof_base + blockIdx.y, domain, idx);
+// SALT_SIZE random columns appended to a blinded oracle's LDE matrix (they are leaf data only, not polynomials).
+// Element idx = s * N + pos; one thread = one PRF block = eight consecutive positions of one salt column.
+__global__ void k_fill_salt(u64* __restrict__ salt_cols, size_t batch_stride, size_t N, p2::ZkKey key, u64 proof_base, u64 domain) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = p2::SALT_SIZE * N;
+    if (8 * t >= total) return;
+    u64 v[8];
+    p2::zk_block(key, proof_base + blockIdx.y, domain, t, v);
+    u64* o = salt_cols + (size_t)blockIdx.y * batch_stride + 8 * t;
+    for (int j = 0; j < 8; j++)
+        if (8 * t + j < total) o[j] = v[j];
 }
 
 struct LutRowsArgs {

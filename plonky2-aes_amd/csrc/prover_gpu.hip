@@ -11,6 +11,7 @@
 #include <string>
 
 #include "capi_common.h"
+#include "os_random.h"
 #include "kernels.h"
 #include "kernels2.h"
 
@@ -75,7 +76,8 @@ struct p2_circuit {
     LookupRows* d_lookup_rows = nullptr;
     int32_t* d_pos_index = nullptr;  // [n] advice block of a PoseidonGate row, else -1
     u32 *d_blind_rows = nullptr, *d_blind_zrows = nullptr;
-    u64 zk_seed = 0, zk_counter = 0;  // keyed blinding randomness (zk circuits)
+    ZkKey zk_key{};      // blinding PRF key (zk circuits): OS randomness at load, or p2_circuit_set_zk_key
+    u64 zk_counter = 0;  // proofs attempted under this key; never reused, also when a batch fails
     size_t total_lut_entries = 0;
     u64 *d_sigmas = nullptr, *d_k_is = nullptr, *d_subgroup = nullptr;
     u64 *d_tw_fwd = nullptr, *d_tw_inv = nullptr;  // w^k / w^-k for k < n_max/2, n_max = n
@@ -102,6 +104,15 @@ struct p2_circuit {
     bool witness_recorded = false;
     u32 ws_inputs = 0;
     size_t chunk = 0, ws_alloc_begin = 0;  // allocs[ws_alloc_begin..] belong to the workspaces
+    bool ws_allocs_open = false;
+    // tuning options (p2_circuit_set_option; the environment is read ONCE, at load): proofs per chunk, proving streams,
+    // phase timing of the host path on stderr
+    size_t opt_chunk = 128, opt_streams = 2;
+    bool opt_debug_timing = false;
+    // host-path staging (p2_prove_batch): persistent device buffers + pinned host buffers, one set per concurrent caller
+    std::vector<struct Staging*> staging_free;
+    std::mutex staging_mu;
+    long fail_alloc_after = -1;            // test hook, see dalloc_ws
     // timing
     bool timing_on = false;
     std::map<std::string, std::pair<float, u32>> times;
@@ -453,89 +464,130 @@ static int circuit_setup(p2_circuit* C) {
 
 static int setup_polyrefs(p2_circuit* C);
 static void collect_timing(p2_circuit* C);
-static int alloc_workspace(p2_circuit* C, size_t chunk, u32 n_inputs, size_t nstreams) {
+// Drains and releases every per-stream workspace; the handle is left with none (chunk == 0), ready to allocate again.
+static void release_workspaces(p2_circuit* C) {
+    for (Workspace* W : C->ws) {
+        if (W->stream) (void)hipStreamSynchronize(W->stream);
+        for (auto& pe : W->pending) {
+            (void)hipEventDestroy(pe.second.first);
+            (void)hipEventDestroy(pe.second.second);
+        }
+        if (W->stream) (void)hipStreamDestroy(W->stream);
+        if (W->done) (void)hipEventDestroy(W->done);
+        delete W;
+    }
+    C->ws.clear();
+    if (C->ws_allocs_open) {
+        for (size_t i = C->ws_alloc_begin; i < C->allocs.size(); i++) (void)hipFree(C->allocs[i]);
+        C->allocs.resize(C->ws_alloc_begin);
+        C->ws_allocs_open = false;
+    }
+    C->chunk = 0;
+    C->ws_inputs = 0;
+    C->cur = nullptr;
+    C->witness_recorded = false;
+}
+// Test hook (P2AES_TEST_FAIL_ALLOC_AFTER=k in the environment when the handle is loaded): the k-th workspace allocation
+// fails as if the device were out of memory.  Exercises the roll-back below without needing a full HBM.
+static int dalloc_ws(p2_circuit* C, size_t& counter, void** p, size_t bytes) {
+    if (C->fail_alloc_after >= 0 && (long)counter++ == C->fail_alloc_after) {
+        C->fail_alloc_after = -1;  // one shot: the retry must succeed
+        return set_error("hipMalloc: injected allocation failure (test hook)"), P2_ERR_HIP;
+    }
+    void* q = nullptr;
+    HIPCHECK(hipMalloc(&q, std::max<size_t>(bytes, 8)));
+    C->allocs.push_back(q);
+    *p = q;
+    return 0;
+}
+static int build_workspace(p2_circuit* C, Workspace* W, size_t chunk, u32 ws_inputs, size_t& counter) {
     const Circuit& c = C->c;
     const size_t n = C->n, N = C->N;
     const u32 zc = c.num_zs_cols(), qc = c.num_quotient_cols(), NC = c.cfg.num_challenges, act = C->active_wires;
+    if (hipStreamCreateWithFlags(&W->stream, hipStreamNonBlocking) != hipSuccess) return set_error("hipStreamCreate failed"), P2_ERR_HIP;
+    if (hipEventCreateWithFlags(&W->done, hipEventDisableTiming) != hipSuccess) return set_error("hipEventCreate failed"), P2_ERR_HIP;
+#define WS_ALLOC(field, count)                                                                       \
+    if (dalloc_ws(C, counter, (void**)&(field), (size_t)(count) * sizeof(*(field)))) return P2_ERR_HIP
+    WS_ALLOC(W->d_input_slots, ws_inputs);
+    WS_ALLOC(W->d_input_values, chunk * ws_inputs);
+    WS_ALLOC(W->d_values, chunk * c.num_slots);
+    WS_ALLOC(W->d_mult, chunk * std::max<size_t>(C->total_lut_entries, 1));
+    WS_ALLOC(W->d_status, chunk);
+    WS_ALLOC(W->d_advice, chunk * std::max<size_t>(c.poseidon_rows.size(), 1) * 55);
+    WS_ALLOC(W->d_wires, chunk * act * n);
+    WS_ALLOC(W->d_wcoef, chunk * act * n);
+    WS_ALLOC(W->d_wlde, chunk * (act + c.salt()) * N);
+    WS_ALLOC(W->d_zs, chunk * zc * n);
+    WS_ALLOC(W->d_zcoef, chunk * zc * n);
+    WS_ALLOC(W->d_zlde, chunk * (zc + c.salt()) * N);
+    WS_ALLOC(W->d_permq, chunk * NC * (c.num_partial_products() + 1) * n);
+    WS_ALLOC(W->d_lktmp, chunk * NC * (c.num_sldc_polys() + 1) * n);
+    WS_ALLOC(W->d_qvals, chunk * NC * N);
+    WS_ALLOC(W->d_qres, chunk * NC * N);
+    WS_ALLOC(W->d_qcoef, chunk * qc * n);
+    WS_ALLOC(W->d_qlde, chunk * (qc + c.salt()) * N);
+    for (Tree* t : {&W->wtree, &W->ztree, &W->qtree}) {
+        t->bits = C->lde_bits;
+        WS_ALLOC(t->dig, chunk * t->stride());
+    }
+    WS_ALLOC(W->d_chal_state, chunk);
+    WS_ALLOC(W->d_chal, chunk * CH_WORDS);
+    WS_ALLOC(W->d_pows, chunk * 8 * n);
+    WS_ALLOC(W->d_ev, chunk * 2 * C->ev_count);
+    WS_ALLOC(W->d_obs, chunk * 2 * C->n_obs);
+    WS_ALLOC(W->d_comp, chunk * 4 * n);
+    WS_ALLOC(W->d_apow, chunk * 2 * APOW_STRIDE);
+    u32 logn_r = C->logn;
+    for (u32 r = 0; r <= C->arities.size(); r++) {
+        size_t n_r = (size_t)1 << logn_r;
+        WS_ALLOC(W->d_fri_coef[r], chunk * 2 * n_r);
+        if (r < C->arities.size()) {
+            WS_ALLOC(W->d_fri_vals[r], chunk * 2 * 8 * n_r);
+            W->fri_tree[r].bits = logn_r + c.cfg.rate_bits - C->arities[r];
+            WS_ALLOC(W->fri_tree[r].dig, chunk * W->fri_tree[r].stride());
+            logn_r -= C->arities[r];
+        }
+    }
+    WS_ALLOC(W->d_pow_best, chunk);
+    WS_ALLOC(W->d_proofs, chunk * C->pbytes);
+#undef WS_ALLOC
+    C->cur = W;
+    int e = setup_polyrefs(C);
+    C->cur = nullptr;
+    return e;
+}
+// Makes sure `nstreams` workspaces of `chunk` proofs and `n_inputs` input targets exist.  All-or-nothing: the new shape
+// (C->chunk, C->ws_inputs, C->ws) is published only after every allocation has succeeded; on failure whatever was
+// allocated is released and the handle is left without workspaces, so that a retry (with a smaller batch) allocates
+// afresh instead of launching kernels on null pointers.
+static int alloc_workspace(p2_circuit* C, size_t chunk, u32 n_inputs, size_t nstreams) {
     if (C->chunk >= chunk && C->ws_inputs >= n_inputs && C->ws.size() >= nstreams) return 0;
-    const size_t old_streams = C->ws.size();
     if (C->chunk != 0) {
         // a later call wants a bigger shape (a first prove(pw) sizes the workspace for one proof; a batch follows):
         // drain the proving streams, release the old workspaces and allocate the larger ones
         if (C->timing_on) collect_timing(C);
-        for (Workspace* W : C->ws) {
-            HIPCHECK(hipStreamSynchronize(W->stream));
-            for (auto& pe : W->pending) {
-                (void)hipEventDestroy(pe.second.first);
-                (void)hipEventDestroy(pe.second.second);
-            }
-            (void)hipStreamDestroy(W->stream);
-            (void)hipEventDestroy(W->done);
-            delete W;
-        }
-        C->ws.clear();
-        for (size_t i = C->ws_alloc_begin; i < C->allocs.size(); i++) (void)hipFree(C->allocs[i]);
-        C->allocs.resize(C->ws_alloc_begin);
         chunk = std::max(chunk, C->chunk);
         n_inputs = std::max(n_inputs, C->ws_inputs);
-        nstreams = std::max(nstreams, old_streams);
+        nstreams = std::max(nstreams, C->ws.size());
+        release_workspaces(C);
     }
     C->ws_alloc_begin = C->allocs.size();
-    C->chunk = chunk;
-    C->ws_inputs = std::max<u32>(n_inputs, 1);
-    int e = 0;
-    for (size_t wi = 0; wi < nstreams && !e; wi++) {
-    Workspace* W = new Workspace();
-    C->ws.push_back(W);
-    C->cur = W;
-    if (hipStreamCreateWithFlags(&W->stream, hipStreamNonBlocking) != hipSuccess) return set_error("hipStreamCreate failed"), P2_ERR_HIP;
-    if (hipEventCreateWithFlags(&W->done, hipEventDisableTiming) != hipSuccess) return set_error("hipEventCreate failed"), P2_ERR_HIP;
-    e |= dalloc(C, &W->d_input_slots, C->ws_inputs);
-    e |= dalloc(C, &C->cur->d_input_values, chunk * C->ws_inputs);
-    e |= dalloc(C, &C->cur->d_values, chunk * c.num_slots);
-    e |= dalloc(C, &C->cur->d_mult, chunk * std::max<size_t>(C->total_lut_entries, 1));
-    e |= dalloc(C, &C->cur->d_status, chunk);
-    e |= dalloc(C, &C->cur->d_advice, chunk * std::max<size_t>(c.poseidon_rows.size(), 1) * 55);
-    e |= dalloc(C, &C->cur->d_wires, chunk * act * n);
-    e |= dalloc(C, &C->cur->d_wcoef, chunk * act * n);
-    e |= dalloc(C, &C->cur->d_wlde, chunk * (act + c.salt()) * N);
-    e |= dalloc(C, &C->cur->d_zs, chunk * zc * n);
-    e |= dalloc(C, &C->cur->d_zcoef, chunk * zc * n);
-    e |= dalloc(C, &C->cur->d_zlde, chunk * (zc + c.salt()) * N);
-    e |= dalloc(C, &C->cur->d_permq, chunk * NC * (c.num_partial_products() + 1) * n);
-    e |= dalloc(C, &C->cur->d_lktmp, chunk * NC * (c.num_sldc_polys() + 1) * n);
-    e |= dalloc(C, &C->cur->d_qvals, chunk * NC * N);
-    e |= dalloc(C, &C->cur->d_qres, chunk * NC * N);
-    e |= dalloc(C, &C->cur->d_qcoef, chunk * qc * n);
-    e |= dalloc(C, &C->cur->d_qlde, chunk * (qc + c.salt()) * N);
-    for (Tree* t : {&C->cur->wtree, &C->cur->ztree, &C->cur->qtree}) {
-        t->bits = C->lde_bits;
-        e |= dalloc(C, &t->dig, chunk * t->stride());
-    }
-    e |= dalloc(C, &C->cur->d_chal_state, chunk);
-    e |= dalloc(C, &C->cur->d_chal, chunk * CH_WORDS);
-    e |= dalloc(C, &C->cur->d_pows, chunk * 8 * n);
-    e |= dalloc(C, &C->cur->d_ev, chunk * 2 * C->ev_count);
-    e |= dalloc(C, &C->cur->d_obs, chunk * 2 * C->n_obs);
-    e |= dalloc(C, &C->cur->d_comp, chunk * 4 * n);
-    e |= dalloc(C, &C->cur->d_apow, chunk * 2 * APOW_STRIDE);
-    u32 logn_r = C->logn;
-    for (u32 r = 0; r <= C->arities.size(); r++) {
-        size_t n_r = (size_t)1 << logn_r;
-        e |= dalloc(C, &C->cur->d_fri_coef[r], chunk * 2 * n_r);
-        if (r < C->arities.size()) {
-            e |= dalloc(C, &C->cur->d_fri_vals[r], chunk * 2 * 8 * n_r);
-            C->cur->fri_tree[r].bits = logn_r + c.cfg.rate_bits - C->arities[r];
-            e |= dalloc(C, &C->cur->fri_tree[r].dig, chunk * C->cur->fri_tree[r].stride());
-            logn_r -= C->arities[r];
+    C->ws_allocs_open = true;
+    const u32 ws_inputs = std::max<u32>(n_inputs, 1);
+    size_t counter = 0;
+    for (size_t wi = 0; wi < nstreams; wi++) {
+        Workspace* W = new Workspace();
+        C->ws.push_back(W);  // owned by the handle from here on: release_workspaces() frees a half-built one too
+        if (build_workspace(C, W, chunk, ws_inputs, counter)) {
+            std::string why = g_last_error;
+            release_workspaces(C);
+            set_error("workspace allocation failed (" + why + "); the handle holds no workspace now, a smaller batch may fit");
+            return P2_ERR_HIP;
         }
     }
-    e |= dalloc(C, &C->cur->d_pow_best, chunk);
-    e |= dalloc(C, &C->cur->d_proofs, chunk * C->pbytes);
-    e |= setup_polyrefs(C);
-    }
-    C->cur = nullptr;
-    return e ? P2_ERR_HIP : 0;
+    C->chunk = chunk;
+    C->ws_inputs = ws_inputs;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------- the pipeline
@@ -590,9 +642,9 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         LAUNCH(C, "fill_advice", k_fill_advice, g1((size_t)55 * n, 256, B), dim3(256), 0, C->d_pos_index, C->cur->d_advice, C->cur->d_wires, (u32)n,
                (u32)c.poseidon_rows.size(), ws);
     if (c.cfg.zero_knowledge) {
-        size_t cnt = c.blind_rows.size() * 135 + c.blind_zrows.size() * 80;
+        size_t cnt = (c.blind_rows.size() * 135 + 7) / 8 + (c.blind_zrows.size() * 80 + 7) / 8;  // PRF blocks of eight elements
         LAUNCH(C, "fill_blind", k_fill_blind, g1(std::max<size_t>(cnt, 1), 256, B), dim3(256), 0, C->d_blind_rows, (u32)c.blind_rows.size(), C->d_blind_zrows,
-               (u32)c.blind_zrows.size(), C->cur->d_wires, ws, (u32)n, C->zk_seed, proof_base);
+               (u32)c.blind_zrows.size(), C->cur->d_wires, ws, (u32)n, C->zk_key, proof_base);
     }
     if (!c.luts.empty()) {
         LutRowsArgs a{};
@@ -611,7 +663,7 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
     // 2. wires commitment
     if (intt_cols(C, C->cur->d_wires, C->cur->d_wcoef, act, ws, B, C->cur->d_wlde, wls)) return P2_ERR_HIP;
     if (lde_cols(C, C->cur->d_wcoef, ws, C->cur->d_wlde, wls, act, 0, B)) return P2_ERR_HIP;
-    if (salt) LAUNCH(C, "fill_salt", k_fill_salt, g1((size_t)salt * N, 256, B), dim3(256), 0, C->cur->d_wlde + (size_t)act * N, wls, N, C->zk_seed, proof_base, (u64)ZK_SALT + 1);
+    if (salt) LAUNCH(C, "fill_salt", k_fill_salt, g1((size_t)salt * N / 8, 256, B), dim3(256), 0, C->cur->d_wlde + (size_t)act * N, wls, N, C->zk_key, proof_base, (u64)ZK_SALT + 1);
     if (merkle_build(C, C->cur->d_wlde, c.cfg.num_wires + salt, act + salt, N, wls, C->cur->wtree, B)) return P2_ERR_HIP;
     // 3. betas, gammas, deltas
     if (challenger(C, 0, C->cur->wtree.dig + cap_off(C->cur->wtree, cap_h), C->cur->wtree.stride(), cap_words, nlp ? 1 : 0, 0, B)) return P2_ERR_HIP;
@@ -644,7 +696,7 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
     // 6. zs commitment, alphas
     if (intt_cols(C, C->cur->d_zs, C->cur->d_zcoef, zc, zs_s, B, C->cur->d_zlde, zl_s)) return P2_ERR_HIP;
     if (lde_cols(C, C->cur->d_zcoef, zs_s, C->cur->d_zlde, zl_s, zc, 0, B)) return P2_ERR_HIP;
-    if (salt) LAUNCH(C, "fill_salt", k_fill_salt, g1((size_t)salt * N, 256, B), dim3(256), 0, C->cur->d_zlde + (size_t)zc * N, zl_s, N, C->zk_seed, proof_base, (u64)ZK_SALT + 2);
+    if (salt) LAUNCH(C, "fill_salt", k_fill_salt, g1((size_t)salt * N / 8, 256, B), dim3(256), 0, C->cur->d_zlde + (size_t)zc * N, zl_s, N, C->zk_key, proof_base, (u64)ZK_SALT + 2);
     if (merkle_build(C, C->cur->d_zlde, zc + salt, zc + salt, N, zl_s, C->cur->ztree, B)) return P2_ERR_HIP;
     if (challenger(C, 1, C->cur->ztree.dig + cap_off(C->cur->ztree, cap_h), C->cur->ztree.stride(), cap_words, 0, 0, B)) return P2_ERR_HIP;
     // 7. quotient
@@ -729,7 +781,7 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
                C->d_w8inv, C->d_qscale);
     }
     if (lde_cols(C, C->cur->d_qcoef, (size_t)qc * n, C->cur->d_qlde, ql_s, qc, 0, B)) return P2_ERR_HIP;
-    if (salt) LAUNCH(C, "fill_salt", k_fill_salt, g1((size_t)salt * N, 256, B), dim3(256), 0, C->cur->d_qlde + (size_t)qc * N, ql_s, N, C->zk_seed, proof_base, (u64)ZK_SALT + 3);
+    if (salt) LAUNCH(C, "fill_salt", k_fill_salt, g1((size_t)salt * N / 8, 256, B), dim3(256), 0, C->cur->d_qlde + (size_t)qc * N, ql_s, N, C->zk_key, proof_base, (u64)ZK_SALT + 3);
     if (merkle_build(C, C->cur->d_qlde, qc + salt, qc + salt, N, ql_s, C->cur->qtree, B)) return P2_ERR_HIP;
     if (challenger(C, 2, C->cur->qtree.dig + cap_off(C->cur->qtree, cap_h), C->cur->qtree.stride(), cap_words, c.degree_bits, 0, B)) return P2_ERR_HIP;
     // 8. openings
@@ -864,6 +916,66 @@ static void collect_timing(p2_circuit* C) {
     }
 }
 
+// Host-path staging: device buffers, pinned host mirrors and a stream, kept across p2_prove_batch calls (they only grow).
+// A caller leases one set for the duration of its call; concurrent callers on one handle each get their own.
+struct Staging {
+    hipStream_t stream = nullptr;
+    u64 *d_vals = nullptr, *h_vals = nullptr;
+    uint8_t *d_proofs = nullptr, *h_proofs = nullptr;
+    int *d_stat = nullptr, *h_stat = nullptr;
+    size_t cap_vals = 0, cap_proofs = 0, cap_stat = 0;
+    void release() {
+        if (d_vals) (void)hipFree(d_vals);
+        if (d_proofs) (void)hipFree(d_proofs);
+        if (d_stat) (void)hipFree(d_stat);
+        if (h_vals) (void)hipHostFree(h_vals);
+        if (h_proofs) (void)hipHostFree(h_proofs);
+        if (h_stat) (void)hipHostFree(h_stat);
+        if (stream) (void)hipStreamDestroy(stream);
+        *this = Staging();
+    }
+    template <class T>
+    static bool grow(T** d, T** h, size_t* cap, size_t bytes) {
+        if (*cap >= bytes) return true;
+        if (*d) (void)hipFree(*d);
+        if (*h) (void)hipHostFree(*h);
+        *d = nullptr, *h = nullptr, *cap = 0;
+        size_t want = bytes + bytes / 4;
+        if (hipMalloc((void**)d, want) != hipSuccess || hipHostMalloc((void**)h, want, hipHostMallocDefault) != hipSuccess) return false;
+        *cap = want;
+        return true;
+    }
+};
+struct StagingLease {
+    p2_circuit* C;
+    Staging* S = nullptr;
+    explicit StagingLease(p2_circuit* c) : C(c) {}
+    Staging* get(size_t vals_bytes, size_t proofs_bytes, size_t batch) {
+        {
+            std::lock_guard<std::mutex> lock(C->staging_mu);
+            if (!C->staging_free.empty()) {
+                S = C->staging_free.back();
+                C->staging_free.pop_back();
+            }
+        }
+        if (!S) S = new Staging();
+        if ((!S->stream && hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking) != hipSuccess) ||
+            !Staging::grow(&S->d_vals, &S->h_vals, &S->cap_vals, vals_bytes) || !Staging::grow(&S->d_proofs, &S->h_proofs, &S->cap_proofs, proofs_bytes) ||
+            !Staging::grow(&S->d_stat, &S->h_stat, &S->cap_stat, batch * sizeof(int))) {
+            set_error("staging buffers for p2_prove_batch could not be allocated");
+            S->release();
+            delete S;
+            S = nullptr;
+        }
+        return S;
+    }
+    ~StagingLease() {
+        if (!S) return;
+        std::lock_guard<std::mutex> lock(C->staging_mu);
+        C->staging_free.push_back(S);
+    }
+};
+
 extern "C" {
 
 int p2_gpu_device_count(void) {
@@ -899,10 +1011,12 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
         C->arities = c.reduction_arity_bits();
         // routed-only gates leave wires 80..134 identically zero (never materialised); PoseidonGate rows use all 135
         C->active_wires = (c.poseidon_rows.empty() && !c.cfg.zero_knowledge) ? c.cfg.num_routed_wires : c.cfg.num_wires;
-        {
-            std::random_device rd;
-            C->zk_seed = ((u64)rd() << 32) ^ rd();
-        }
+        for (int i = 0; i < 4; i++) C->zk_key.k[i] = os_random_field();
+        // environment defaults for the options, read once here (never per call)
+        if (const char* e = getenv("P2AES_CHUNK")) C->opt_chunk = (size_t)std::max(1, atoi(e));
+        if (const char* e = getenv("P2AES_STREAMS")) C->opt_streams = (size_t)std::min(8, std::max(1, atoi(e)));
+        C->opt_debug_timing = getenv("P2AES_DEBUG_TIMING") != nullptr;
+        if (const char* e = getenv("P2AES_TEST_FAIL_ALLOC_AFTER")) C->fail_alloc_after = atol(e);
         C->pbytes = proof_bytes(c);
         if (hipSetDevice(device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
         if (hipStreamCreate(&C->stream) != hipSuccess) throw std::runtime_error("hipStreamCreate failed");
@@ -955,12 +1069,12 @@ void p2_circuit_free(p2_circuit* C) {
     if (!C) return;
     (void)hipSetDevice(C->device);
     (void)hipDeviceSynchronize();
-    for (void* p : C->allocs) (void)hipFree(p);
-    for (Workspace* W : C->ws) {
-        if (W->stream) (void)hipStreamDestroy(W->stream);
-        if (W->done) (void)hipEventDestroy(W->done);
-        delete W;
+    release_workspaces(C);
+    for (Staging* S : C->staging_free) {
+        S->release();
+        delete S;
     }
+    for (void* p : C->allocs) (void)hipFree(p);
     if (C->stream) (void)hipStreamDestroy(C->stream);
     if (C->ev_witness) (void)hipEventDestroy(C->ev_witness);
     delete C;
@@ -973,11 +1087,15 @@ int p2_circuit_verifier_data(const p2_circuit* C, uint64_t* out, size_t cap, siz
     return P2_OK;
 }
 size_t p2_circuit_proof_bytes(const p2_circuit* C) { return C->pbytes; }
-int p2_circuit_set_zk_seed(p2_circuit* C, uint64_t seed) {
+int p2_circuit_set_zk_key(p2_circuit* C, const uint64_t key[4]) {
     std::lock_guard<std::mutex> lock(C->mu);
-    C->zk_seed = seed;
+    for (int i = 0; i < 4; i++) C->zk_key.k[i] = key[i] % gl::P;
     C->zk_counter = 0;
     return P2_OK;
+}
+int p2_circuit_set_zk_seed(p2_circuit* C, uint64_t seed) {
+    const uint64_t key[4] = {seed, 0, 0, 0};
+    return p2_circuit_set_zk_key(C, key);
 }
 
 static int setup_polyrefs(p2_circuit* C) {
@@ -1015,13 +1133,11 @@ int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets,
         if (slot < 0) return set_error("input target is not a target of this circuit"), P2_ERR_INVALID;
         slots[i] = (u32)slot;
     }
-    // Chunk size / stream count: P2AES_CHUNK (default 128 proofs per chunk), P2AES_STREAMS (default 2).  A batch smaller
+    // Chunk size / stream count: options "chunk" (default 128 proofs per chunk) and "streams" (default 2).  A batch smaller
     // than chunk x streams is split evenly over the streams, so that the serial stages of one chunk (witness levels,
     // the Fiat-Shamir chain, proof-of-work) overlap the wide kernels of the other.  A later, larger batch regrows the
     // workspaces (alloc_workspace); a smaller one runs in the existing ones.
-    size_t want_chunk = 128, want_streams = 2;
-    if (const char* e = getenv("P2AES_CHUNK")) want_chunk = std::max(1, atoi(e));
-    if (const char* e = getenv("P2AES_STREAMS")) want_streams = std::min(8, std::max(1, atoi(e)));
+    size_t want_chunk = C->opt_chunk, want_streams = C->opt_streams;
     {
         // cap the chunk so that all workspaces fit in ~70% of the HBM that is free (plus what the workspaces hold now)
         const Circuit& c = C->c;
@@ -1043,10 +1159,20 @@ int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets,
     // inputs) and the caller's stream then waits for the proofs.  NULL means the legacy default stream, which is
     // ordered the same way (an event recorded on stream 0) -- no device-wide synchronisation, so consecutive calls
     // pipeline into each other.
-    hipEvent_t ev_in = nullptr;
-    HIPCHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+    struct EventGuard {
+        hipEvent_t e = nullptr;
+        ~EventGuard() {
+            if (e) (void)hipEventDestroy(e);
+        }
+    } ev_guard;
+    HIPCHECK(hipEventCreateWithFlags(&ev_guard.e, hipEventDisableTiming));
+    hipEvent_t ev_in = ev_guard.e;
     HIPCHECK(hipEventRecord(ev_in, caller));
     for (Workspace* W : C->ws) HIPCHECK(hipStreamWaitEvent(W->stream, ev_in, 0));
+    // the blinding counter advances before anything is enqueued: a batch that fails half-way must not leave its proof
+    // indices to be used again under the same key
+    const u64 proof_base0 = C->zk_counter;
+    C->zk_counter += batch;
     size_t k = 0;
     for (size_t done = 0; done < batch; done += C->chunk, k++) {
         u32 B = (u32)std::min(C->chunk, batch - done);
@@ -1056,16 +1182,14 @@ int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets,
             HIPCHECK(hipMemcpy(C->cur->d_input_slots, slots.data(), n_targets * 4, hipMemcpyHostToDevice));
             C->cur->h_input_slots = slots;
         }
-        int rc = prove_chunk(C, B, (u32)n_targets, d_values + done * n_targets, d_proofs + done * C->pbytes, d_status + done, C->zk_counter + done);
+        int rc = prove_chunk(C, B, (u32)n_targets, d_values + done * n_targets, d_proofs + done * C->pbytes, d_status + done, proof_base0 + done);
         C->cur = nullptr;
         if (rc) return rc;
     }
-    C->zk_counter += batch;
     for (Workspace* W : C->ws) {
         HIPCHECK(hipEventRecord(W->done, W->stream));
         HIPCHECK(hipStreamWaitEvent(caller, W->done, 0));
     }
-    HIPCHECK(hipEventDestroy(ev_in));
     return P2_OK;
 }
 
@@ -1084,64 +1208,85 @@ int p2_prove_batch(p2_circuit* C, size_t batch, const p2_assignment* inputs, uin
     // Fast path: every PartialWitness assigns the same target list in the same order.  Otherwise the batch is put on
     // the union of the targets, a witness that does not assign a target gets the "absent" marker (2^64-1, not a field
     // element), and a witness that assigns one target two different values fails on the host like set_target does.
+    // Either way a value that is not a canonical field element fails that witness here, on the host.
     size_t nt = inputs[0].count;
     bool same = true;
     for (size_t i = 1; i < batch && same; i++) same = inputs[i].count == nt && memcmp(inputs[i].targets, inputs[0].targets, nt * 8) == 0;
-    std::vector<u64> union_targets, hv;
+    std::vector<u64> union_targets;
+    std::map<u64, size_t> col;
     std::vector<int> host_status(batch, 0);
     const p2_target* targets = inputs[0].targets;
-    if (same) {
-        hv.resize(batch * std::max<size_t>(nt, 1));
-        for (size_t i = 0; i < batch; i++)
-            for (size_t k = 0; k < nt; k++) hv[i * nt + k] = inputs[i].values[k];
-    } else {
-        std::map<u64, size_t> col;
+    if (!same) {
         for (size_t i = 0; i < batch; i++)
             for (size_t k = 0; k < inputs[i].count; k++)
                 if (col.emplace(inputs[i].targets[k], union_targets.size()).second) union_targets.push_back(inputs[i].targets[k]);
         nt = union_targets.size();
-        hv.assign(batch * std::max<size_t>(nt, 1), ~0ull);
+        targets = union_targets.data();
+    }
+    const size_t nvals = batch * std::max<size_t>(nt, 1);
+    StagingLease lease(C);
+    Staging* S = lease.get(nvals * 8, batch * C->pbytes, batch);
+    if (!S) return P2_ERR_HIP;
+    const auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const bool dbg = C->opt_debug_timing;
+    double t_a = now();
+    u64* hv = S->h_vals;  // pinned: the values are laid out straight into the buffer the DMA engine reads
+    if (same) {
+        for (size_t i = 0; i < batch; i++)
+            for (size_t k = 0; k < nt; k++) {
+                u64 v = inputs[i].values[k];
+                if (v >= gl::P) host_status[i] = P2_PROOF_WITNESS_CONFLICT, v = 0;
+                hv[i * nt + k] = v;
+            }
+    } else {
+        std::fill(hv, hv + nvals, ~0ull);
         for (size_t i = 0; i < batch; i++)
             for (size_t k = 0; k < inputs[i].count; k++) {
                 u64& cell = hv[i * nt + col[inputs[i].targets[k]]];
                 u64 v = inputs[i].values[k];
-                if (v >= gl::P || (cell != ~0ull && cell != v)) host_status[i] = P2_PROOF_WITNESS_CONFLICT;
+                if (v >= gl::P || (cell != ~0ull && cell != v)) host_status[i] = P2_PROOF_WITNESS_CONFLICT, v = 0;
                 cell = v;
             }
-        targets = union_targets.data();
     }
-    u64* d_vals = nullptr;
-    uint8_t* d_proofs = nullptr;
-    int* d_stat = nullptr;
-    const bool dbg = getenv("P2AES_DEBUG_TIMING") != nullptr;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_a = now();
-    HIPCHECK(hipMalloc((void**)&d_vals, hv.size() * 8));
-    HIPCHECK(hipMalloc((void**)&d_proofs, batch * C->pbytes));
-    HIPCHECK(hipMalloc((void**)&d_stat, batch * sizeof(int)));
-    HIPCHECK(hipMemcpy(d_vals, hv.data(), hv.size() * 8, hipMemcpyHostToDevice));
     double t_b = now();
-    int rc = p2_prove_batch_device(C, batch, targets, nt, d_vals, d_proofs, d_stat, nullptr);
-    double t_c = now();
-    if (rc == P2_OK) rc = p2_circuit_synchronize(C);
-    double t_d = now();
-    if (dbg) fprintf(stderr, "[p2aes] alloc+h2d %.3f enqueue %.3f wait %.3f s\n", t_b - t_a, t_c - t_b, t_d - t_c);
-    if (rc == P2_OK) {
-        if (hipMemcpy(proofs, d_proofs, batch * C->pbytes, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(status, d_stat, batch * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
-            set_error("copying proofs back failed");
-            rc = P2_ERR_HIP;
-        }
-        if (dbg) fprintf(stderr, "[p2aes] copy back %.3f s\n", now() - t_d);
-        for (size_t i = 0; i < batch && rc == P2_OK; i++)
-            if (host_status[i]) {
-                status[i] = host_status[i];
-                memset(proofs + i * C->pbytes, 0, C->pbytes);
-            }
+    // one stream carries upload -> prove -> download; p2_prove_batch_device orders the proving streams with it
+    HIPCHECK(hipMemcpyAsync(S->d_vals, hv, nvals * 8, hipMemcpyHostToDevice, S->stream));
+    int rc = p2_prove_batch_device(C, batch, targets, nt, S->d_vals, S->d_proofs, S->d_stat, (void*)S->stream);
+    if (rc != P2_OK) {
+        (void)hipStreamSynchronize(S->stream);
+        return rc;
     }
-    (void)hipFree(d_vals);
-    (void)hipFree(d_proofs);
-    (void)hipFree(d_stat);
-    return rc;
+    HIPCHECK(hipMemcpyAsync(S->h_proofs, S->d_proofs, batch * C->pbytes, hipMemcpyDeviceToHost, S->stream));
+    HIPCHECK(hipMemcpyAsync(S->h_stat, S->d_stat, batch * sizeof(int), hipMemcpyDeviceToHost, S->stream));
+    double t_c = now();
+    HIPCHECK(hipStreamSynchronize(S->stream));
+    double t_d = now();
+    memcpy(proofs, S->h_proofs, batch * C->pbytes);
+    memcpy(status, S->h_stat, batch * sizeof(int));
+    for (size_t i = 0; i < batch; i++)
+        if (host_status[i]) {
+            status[i] = host_status[i];
+            memset(proofs + i * C->pbytes, 0, C->pbytes);
+        }
+    if (dbg) fprintf(stderr, "[p2aes] pack %.3f enqueue %.3f wait %.3f unpack %.3f s\n", t_b - t_a, t_c - t_b, t_d - t_c, now() - t_d);
+    return P2_OK;
+}
+
+int p2_circuit_set_option(p2_circuit* C, const char* name, long value) {
+    std::lock_guard<std::mutex> lock(C->mu);
+    std::string k(name ? name : "");
+    if (k == "chunk") {
+        if (value < 1 || value > 4096) return set_error("option chunk: 1..4096 proofs"), P2_ERR_INVALID;
+        C->opt_chunk = (size_t)value;
+    } else if (k == "streams") {
+        if (value < 1 || value > 8) return set_error("option streams: 1..8"), P2_ERR_INVALID;
+        C->opt_streams = (size_t)value;
+    } else if (k == "debug_timing") {
+        C->opt_debug_timing = value != 0;
+    } else {
+        return set_error("unknown option (known: chunk, streams, debug_timing)"), P2_ERR_INVALID;
+    }
+    return P2_OK;
 }
 
 int p2_circuit_set_timing(p2_circuit* C, int enable) {

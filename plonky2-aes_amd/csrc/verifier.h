@@ -140,6 +140,11 @@ inline std::string verify_proof(const Circuit& C, const VerifierData& vd, const 
     const size_t n = C.n(), lde_bits = C.degree_bits + C.cfg.rate_bits, N = (size_t)1 << lde_bits;
     const size_t cap_n = (size_t)1 << C.cfg.cap_height;
     const std::vector<u32> arities = C.reduction_arity_bits();
+    // Proof shape (upstream: fri/validate_shape.rs + the fixed layout of ProofWithPublicInputs): the total length and the
+    // depth of every Merkle path are functions of the circuit alone.  Without the depth check a prover could root subtrees
+    // of different depths under different cap entries and pick, per query, which of them to open.  Every count below is
+    // derived from the circuit and every Merkle path depth is checked after parsing, so together with the trailing-bytes
+    // check the total length is pinned as well.
     ProofReader r{bytes, len};
     auto read_cap = [&]() {
         std::vector<Hash4> c(cap_n);
@@ -187,6 +192,32 @@ inline std::string verify_proof(const Circuit& C, const VerifierData& vd, const 
     for (auto* v : {&o_constants, &o_sigmas, &o_wires, &o_zs, &o_zs_next, &o_pp, &o_quot, &o_lk, &o_lk_next, &final_poly})
         for (auto& e : *v)
             if (!canonical(e.a) || !canonical(e.b)) return "non-canonical field element";
+    if (!canonical(pow_witness)) return "non-canonical field element";
+    auto canonical_hashes = [&](const std::vector<Hash4>& hs) {
+        for (auto& h : hs)
+            for (int i = 0; i < 4; i++)
+                if (!canonical(h.e[i])) return false;
+        return true;
+    };
+    if (!canonical_hashes(wires_cap) || !canonical_hashes(zs_cap) || !canonical_hashes(quot_cap)) return "non-canonical field element";
+    for (auto& cap : fri_caps)
+        if (!canonical_hashes(cap)) return "non-canonical field element";
+    for (auto& q : queries) {
+        for (int o = 0; o < 4; o++) {
+            if (q.init_proofs[o].size() + C.cfg.cap_height != lde_bits) return "Merkle path of the wrong depth (initial tree).";
+            if (!canonical_hashes(q.init_proofs[o])) return "non-canonical field element";
+            for (u64 v : q.init_evals[o])
+                if (!canonical(v)) return "non-canonical field element";
+        }
+        size_t bits = lde_bits;
+        for (size_t k = 0; k < arities.size(); k++) {
+            if (q.step_proofs[k].size() + C.cfg.cap_height + arities[k] != bits) return "Merkle path of the wrong depth (FRI round).";
+            if (!canonical_hashes(q.step_proofs[k])) return "non-canonical field element";
+            for (auto& e : q.step_evals[k])
+                if (!canonical(e.a) || !canonical(e.b)) return "non-canonical field element";
+            bits -= arities[k];
+        }
+    }
 
     // ---- challenges (plonk/get_challenges.rs)
     HostChallenger ch;

@@ -20,6 +20,7 @@ def lib():
         L.orc_circuit_free.argtypes = [vp]
         L.orc_degree_bits.restype, L.orc_degree_bits.argtypes = C.c_uint32, [vp]
         L.orc_set_zk.argtypes = [vp, C.c_uint64, C.c_uint64]
+        L.orc_set_zk_key.argtypes = [vp, u64p, C.c_uint64]
         L.orc_set_fault.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64]
         L.orc_row_gate_kind.restype, L.orc_row_gate_kind.argtypes = C.c_uint32, [vp, C.c_uint32]
         L.orc_wire_slot.restype, L.orc_wire_slot.argtypes = C.c_int32, [vp, C.c_uint32, C.c_uint32]
@@ -91,6 +92,9 @@ class OracleCircuit:
     def set_zk(self, seed, proof_index):
         lib().orc_set_zk(self.h, seed, proof_index)
 
+    def set_zk_key(self, key4, proof_index):
+        lib().orc_set_zk_key(self.h, (C.c_uint64 * 4)(*key4), proof_index)
+
     def prove(self, pw_map, trace=False, cap=1 << 22):
         """Returns (status, proof bytes or None)."""
         ts = (C.c_uint64 * len(pw_map))(*pw_map.keys())
@@ -101,6 +105,14 @@ class OracleCircuit:
         if st:
             return st, None
         return 0, buf.raw[: n.value]
+
+    def generate_witness(self, pw_map, cap):
+        """(status, wires [num_wires][n] column-major) -- witness generation only, no proving."""
+        ts = (C.c_uint64 * len(pw_map))(*pw_map.keys())
+        vs = (C.c_uint64 * len(pw_map))(*pw_map.values())
+        out = (C.c_uint64 * cap)()
+        st = lib().orc_generate_witness(self.h, ts, vs, len(pw_map), out)
+        return st, (list(out) if st == 0 else None)
 
     def trace(self, name):
         n = lib().orc_trace_len(self.h, name.encode())

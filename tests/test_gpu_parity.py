@@ -90,6 +90,17 @@ def test_merkle_cap(gpu, orc, cols, leaves):
     assert list(cap) == list(ref)
 
 
+def _check_all_witnesses(data, oc, pws, status):
+    n, W = 1 << data.info["degree_bits"], data.info["num_wires"]
+    for i, (pw, st) in enumerate(zip(pws, status)):
+        ost, wires = oc.generate_witness(pw.map, W * n)
+        assert ost == st, "witness %d: GPU status %d, oracle %d" % (i, st, ost)
+        if st == 0:
+            got = data.debug_read("wires", i, cap=W * n)
+            assert got == wires[:len(got)], "witness %d: GPU wire matrix differs from the oracle's" % i
+            assert not any(wires[len(got):]), "oracle has data in a wire column the GPU treats as identically zero"
+
+
 def _gpu_vs_oracle(gpu, orc, data, pws, exact=1):
     """The whole batch on the GPU; the first `exact` successful proofs must equal the oracle's byte for byte (the oracle
     takes seconds per proof, and the driver's GPU run has a time limit), every failing witness must fail the same way in
@@ -97,6 +108,10 @@ def _gpu_vs_oracle(gpu, orc, data, pws, exact=1):
     oc = orc.OracleCircuit(data.blob)
     assert data.verifier_data() == oc.verifier_data()
     proofs, status = data.prove_batch(pws)
+    # EVERY witness of the batch: the wire matrix the GPU generated against the oracle's witness generator (no oracle
+    # proving time: witness generation is milliseconds on the host) -- skipped where blinding rows make it key-dependent
+    if not data.info.get("zero_knowledge"):
+        _check_all_witnesses(data, oc, pws, status)
     for pw, proof, st in zip(pws, proofs, status):
         if st != 0 or exact > 0:
             ost, ref = oc.prove(pw.map)   # returns at once when witness generation fails
@@ -403,3 +418,142 @@ def test_one_handle_growing_batches_and_changing_target_lists(gpu, orc):
                 data.verify(proof)
                 ref[k] = proof
             assert proof == ref[k]
+
+
+def _stage_table(gpu, orc, data, pw):
+    """Per-stage comparison (tools/gpu_stage_check.py as a test): every intermediate buffer of proof 1 of a two-proof
+    batch against the oracle's trace, in pipeline order, so a regression names its stage."""
+    oc = orc.OracleCircuit(data.blob)
+    st, ref = oc.prove(pw.map, trace=True)
+    assert st == 0
+    proofs, status = data.prove_batch([pw, pw])
+    assert status == [0, 0]
+    n, nr = 1 << data.info["degree_bits"], data.info["num_fri_rounds"]
+    ch = data.debug_read("challenges", 1)
+    fin_ref = oc.trace("fri_final_poly_in")
+    stages = [
+        ("verifier_data", data.verifier_data(), oc.verifier_data()),
+        ("wires", data.debug_read("wires", 1), oc.trace("wires")[:len(data.debug_read("wires", 1))]),
+        ("wires_cap", data.debug_read("wires_cap", 1), oc.trace("wires_cap")),
+        ("betas|gammas", ch[0:4], oc.trace("betas") + oc.trace("gammas")),
+        ("deltas", ch[4:12] if oc.trace("deltas") else [], oc.trace("deltas")),
+        ("zs", data.debug_read("zs", 1), oc.trace("zs")),
+        ("zs_cap", data.debug_read("zs_cap", 1), oc.trace("zs_cap")),
+        ("alphas", ch[12:14], oc.trace("alphas")),
+        ("quotient_coeffs", data.debug_read("quotient_coeffs", 1), oc.trace("quotient_coeffs")),
+        ("quotient_cap", data.debug_read("quotient_cap", 1), oc.trace("quotient_cap")),
+        ("zeta", ch[14:16], oc.trace("zeta")),
+        ("fri_alpha", ch[16:18], oc.trace("fri_alpha")),
+        ("fri_final_poly_in", data.debug_read("fri_final_poly_in", 1), fin_ref[0::2] + fin_ref[1::2]),
+        ("fri_betas", ch[18:18 + 2 * nr], oc.trace("fri_betas")),
+        ("pow_witness", ch[34:35], oc.trace("pow_witness")),
+        ("query_indices", ch[36:36 + 28], oc.trace("query_indices")),
+    ]
+    for name, got, want in stages:
+        assert got == want, "stage %s differs from the oracle (first divergence in pipeline order)" % name
+    assert proofs[0] == ref and proofs[1] == ref
+    data.verify(proofs[1])
+
+
+def test_per_stage_parity_aes_block(gpu, orc):
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "aes_kat.json")))
+    data, pws = circuits.encrypt_block(gpu, bytes.fromhex(kat["fips197_block"]["key"]), bytes.fromhex(kat["fips197_block"]["input"]),
+                                       expected=bytes.fromhex(kat["fips197_block"]["output"]))
+    _stage_table(gpu, orc, data, pws[0])
+
+
+def test_per_stage_parity_aes_gcm_1k(gpu, orc):
+    data, pws, _ = circuits.encrypt(gpu, 4, 1024, False)
+    _stage_table(gpu, orc, data, pws[0])
+
+
+def test_non_canonical_input_value_fails_its_witness(gpu):
+    """A value >= p is not a field element: that witness fails on the host (both the same-target fast path and the
+    union path), the rest of the batch is proved."""
+    data, pws = circuits.gf_2_8_add(gpu, [(1, 2), (3, 4), (5, 6)])
+    bad = gpu.PartialWitness()
+    bad.map = dict(pws[1].map)
+    bad.map[list(bad.map)[0]] = (1 << 64) - 1
+    proofs, status = data.prove_batch([pws[0], bad, pws[2]])          # same targets, same order
+    assert status == [0, 1, 0] and proofs[1] is None
+    shuffled = gpu.PartialWitness()
+    shuffled.map = dict(reversed(list(pws[2].map.items())))
+    bad2 = gpu.PartialWitness()
+    bad2.map = dict(pws[1].map)
+    bad2.map[list(bad2.map)[1]] = P
+    proofs2, status2 = data.prove_batch([shuffled, bad2, pws[0]])     # union path
+    assert status2 == [0, 1, 0] and proofs2[2] == proofs[0] and proofs2[0] == proofs[2]
+
+
+def test_options_change_scheduling_not_proofs(gpu):
+    data, pws = circuits.mix_columns(gpu, circuits.random_states(9, 5))
+    base, st = data.prove_batch(pws)
+    assert st == [0] * 9
+    data2, _ = circuits.mix_columns(gpu, circuits.random_states(9, 5))
+    data2.set_option("chunk", 4)
+    data2.set_option("streams", 1)
+    got, st2 = data2.prove_batch(pws)
+    assert st2 == st and got == base
+    with pytest.raises(gpu.P2Error):
+        data2.set_option("no_such_option", 1)
+    with pytest.raises(gpu.P2Error):
+        data2.set_option("streams", 99)
+
+
+def test_failed_workspace_allocation_is_rolled_back(gpu, monkeypatch):
+    """a hipMalloc failure in the middle of alloc_workspace must leave the handle without workspaces (error
+    code, no kernels on null pointers) and a later call must allocate afresh and succeed."""
+    monkeypatch.setenv("P2AES_TEST_FAIL_ALLOC_AFTER", "17")
+    data, pws = circuits.gf_2_8_add(gpu, [(9, 7), (1, 1)])
+    data.gpu()                                     # the hook is read when the handle is loaded
+    monkeypatch.delenv("P2AES_TEST_FAIL_ALLOC_AFTER")
+    with pytest.raises(gpu.P2Error, match="allocation"):
+        data.prove_batch(pws)
+    proofs, status = data.prove_batch(pws)          # one-shot hook: the retry allocates every buffer again
+    assert status == [0, 0]
+    for p in proofs:
+        data.verify(p)
+    ref, _ = circuits.gf_2_8_add(gpu, [(9, 7), (1, 1)])
+    assert ref.prove_batch(pws)[0] == proofs
+
+
+def test_same_blob_on_every_visible_device(gpu):
+    """Multi-GPU path by construction: the compiled circuit is replicated per device, proofs are independent.
+    Load the blob on every visible device: equal verifier data, byte-equal proofs.  (One device on this pool.)"""
+    ndev = gpu.lib().p2_gpu_device_count()
+    data0, pws = circuits.mix_columns(gpu, circuits.random_states(3, 4))
+    ref, st = data0.prove_batch(pws)
+    assert st == [0] * 3
+    for dev in range(ndev):
+        d = gpu.CircuitData(data0.blob, device=dev)
+        assert d.verifier_data() == data0.verifier_data()
+        got, st = d.prove_batch(pws)
+        assert st == [0] * 3 and got == ref
+    with pytest.raises(gpu.P2Error):
+        gpu.CircuitData(data0.blob, device=ndev).gpu()
+
+
+def test_zk_full_width_key_and_os_key(gpu, orc):
+    """The blinding PRF takes a 256-bit key: every key word matters, the oracle reproduces proofs under a full key, and
+    two handles with the default (OS-drawn) key blind differently."""
+    data, pws = circuits.zk_gf_2_8_add(gpu, [(5, 9), (7, 7)])
+    oc = orc.OracleCircuit(data.blob)
+    key = [0x0123456789ABCDEF, 0xFFFFFFFF00000000, 0x1111111111111111, 0xFEDCBA9876543210]
+    data.set_zk_key(key)
+    proofs, status = data.prove_batch(pws)
+    assert status == [0, 0]
+    for i in (0, 1):
+        oc.set_zk_key(key, i)
+        st, ref = oc.prove(pws[i].map)
+        assert st == 0 and ref == proofs[i]
+    for w in range(4):
+        k2 = list(key)
+        k2[w] ^= 1
+        data.set_zk_key(k2)
+        assert data.prove_batch(pws[:1])[0][0] != proofs[0]
+    a, _ = circuits.zk_gf_2_8_add(gpu, [(5, 9)])
+    b, _ = circuits.zk_gf_2_8_add(gpu, [(5, 9)])
+    pa, pb = a.prove(pws[0]), b.prove(pws[0])
+    assert pa != pb
+    a.verify(pa)
+    b.verify(pb)

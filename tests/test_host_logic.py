@@ -411,3 +411,132 @@ def test_host_selftest_of_the_shared_arithmetic(pkg):
     assert pkg.lib().p2_selftest_host(0x5EED, 2_000_000, 2_000) == 0
     assert pkg.lib().p2_selftest_host(7, 200_000, 500) == 0
 
+
+
+def test_gate_counts_of_the_report_sizes_list(pkg):
+    """circuit_gcm.rs:708-736 (test_encrypt_report_sizes): builder.num_gates() and the compiled shape for AES-GCM-128/-256,
+    L in 16..2048, against tests/golden/gate_counts.json (this build's own frozen counts -- the reference prints them but
+    holds none; catches builder drift on the CPU)."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "gate_counts.json")))["sizes"]
+    assert len(gold) == 20
+    for e in gold:
+        if e["L"] > 1024 and e["nk"] == 8:
+            continue                                   # the largest one costs the most host time and adds no new shape
+        b = pkg.CircuitBuilder()
+        pkg.AesGcmTarget.build(b, e["nk"], e["nk"] + 6, e["L"], False)
+        assert b.num_gates() == e["num_gates"], e
+        info = b.build().info
+        for k in ("degree_bits", "num_ops", "num_levels", "num_slots", "proof_bytes"):
+            assert info[k] == e[k], (e, k, info[k])
+
+
+def _query_layout(info):
+    """Byte offsets of the Merkle-path length prefixes of query 0 (DESIGN.md 'Proof layout'), non-zk circuits."""
+    lde_bits, cap_h, rounds = info["degree_bits"] + 3, 4, info["num_fri_rounds"]
+    cols = [info["num_constants_cols"] + info["num_routed_wires"], info["num_wires"], info["num_zs_cols"], info["num_quotient_cols"]]
+    qbytes = sum(8 * c + 1 + 32 * (lde_bits - cap_h) for c in cols)
+    bits = lde_bits
+    for _ in range(rounds):
+        bits -= 4
+        qbytes += 16 * 16 + 1 + 32 * (bits - cap_h)
+    fl = (1 << info["degree_bits"]) >> (4 * rounds)
+    q0 = info["proof_bytes"] - 8 - 16 * fl - 28 * qbytes
+    offs, pos = [], q0
+    for c in cols:
+        pos += 8 * c
+        offs.append((pos, lde_bits - cap_h))
+        pos += 1 + 32 * (lde_bits - cap_h)
+    return offs
+
+
+def test_verifier_rejects_merkle_paths_of_the_wrong_depth(pkg, orc):
+    """ADVICE r1 (verifier.h): a proof whose total length is right but whose Merkle paths have other depths -- one path a
+    sibling longer, the next a sibling shorter -- must be rejected for its SHAPE, before any hashing decides."""
+    data, pws = circuits.gf_2_8_mul(pkg, [(0x57, 0x13, 0xFE)])
+    oc, vd, res = _prove_verify(pkg, orc, data, pws)
+    proof = res[0][1]
+    (p0, d0), (p1, d1) = _query_layout(data.info)[:2]
+    assert proof[p0] == d0 and proof[p1] == d1       # the layout helper points at the length prefixes
+    bad = bytearray(proof)
+    bad[p0] = d0 + 1                                 # path 0 claims one sibling more ...
+    bad[p0 + 1 + 32 * d0: p0 + 1 + 32 * d0] = bytes(32)
+    q1 = p1 + 32                                     # (path 1's prefix moved by the inserted sibling)
+    assert bad[q1] == d1
+    bad[q1] = d1 - 1                                 # ... path 1 one fewer: same total length
+    del bad[q1 + 1 + 32 * (d1 - 1): q1 + 1 + 32 * d1]
+    assert len(bad) == len(proof)
+    with pytest.raises(pkg.P2Error, match="depth"):
+        data.verify(bytes(bad), vd)
+    # non-canonical encodings of field elements are rejected wherever they appear: pow witness, a cap word, a leaf value
+    n = len(proof)
+    for pos in (n - 8, 0, p0 - 8):
+        bad = bytearray(proof)
+        bad[pos:pos + 8] = (0xFFFFFFFFFFFFFFFF).to_bytes(8, "little")
+        with pytest.raises(pkg.P2Error, match="non-canonical"):
+            data.verify(bytes(bad), vd)
+
+
+def test_ecgfp5_default_randomness_is_the_os_csprng(pkg):
+    """keys, nonces and encode_binary padding default to the OS CSPRNG (the reference's OsRng,
+    ecgfp5/src/lib.rs:35,64); the seeded forms are reproducible and test-only."""
+    E = pkg.ecgfp5
+    order = E.group_order()
+    ks = {E.random_scalar() for _ in range(8)}
+    assert len(ks) == 8 and all(0 <= k < order for k in ks)
+    assert max(ks).bit_length() > 300                      # full-width scalars, not 64-bit seeds stretched
+    assert E.random_scalar(7) == E.random_scalar(7) and E.random_scalar(7) != E.random_scalar(8)
+    a, b = E.new_rand_from_subgroup(), E.new_rand_from_subgroup()
+    assert a != b and E.is_in_subgroup(a) and E.is_in_subgroup(b)
+    x = 0x0123456789ABCDEF0123456789ABCDEF01234567
+    p1, p2 = E.encode_binary(x), E.encode_binary(x)
+    assert p1 != p2 and E.decode_binary(p1) == x and E.decode_binary(p2) == x
+    assert E.encode_binary(x, 5) == E.encode_binary(x, 5)
+    sk1, sk2 = pkg.ECGFP5SecretKey.rand(), pkg.ECGFP5SecretKey.rand()
+    assert sk1.value != sk2.value
+    k1, K1 = pkg.poseidon_native.new_key()
+    k2, K2 = pkg.poseidon_native.new_key()
+    assert k1 != k2 and K1 != K2
+
+
+def test_zk_prf_key_is_full_width_in_the_oracle(pkg, orc):
+    """The blinding PRF (circuit.h 'Blinding randomness') is keyed by four field elements: each of them, the proof index
+    and the seed shorthand all change the oracle's zk proof; equal keys reproduce it."""
+    data, pws = circuits.zk_gf_2_8_add(pkg, [(5, 9)])
+    oc = orc.OracleCircuit(data.blob)
+    vd = oc.verifier_data()
+    key = [11, 22, 33, 44]
+    oc.set_zk_key(key, 0)
+    st, base = oc.prove(pws[0].map)
+    assert st == 0
+    data.verify(base, vd)
+    oc.set_zk_key(key, 0)
+    assert oc.prove(pws[0].map)[1] == base
+    seen = {base}
+    for w in range(4):
+        k2 = list(key)
+        k2[w] += 1
+        oc.set_zk_key(k2, 0)
+        seen.add(oc.prove(pws[0].map)[1])
+    oc.set_zk_key(key, 1)
+    seen.add(oc.prove(pws[0].map)[1])
+    assert len(seen) == 6
+    oc.set_zk(99, 3)
+    a = oc.prove(pws[0].map)[1]
+    oc.set_zk_key([99, 0, 0, 0], 3)
+    assert oc.prove(pws[0].map)[1] == a
+
+
+def test_c_abi_functions_do_not_throw_across_the_boundary(pkg):
+    """a bad LUT index / target through a void or target-returning entry point sets p2_last_error and returns the
+    function's error value instead of ending in std::terminate."""
+    import ctypes as C
+    L = pkg.lib()
+    b = pkg.CircuitBuilder()
+    t = b.add_virtual_target()
+    assert L.p2_builder_add_lookup_from_index(b._h, t, 12345) == 0xFFFFFFFFFFFFFFFF
+    assert b"" != L.p2_last_error()
+    out = (C.c_uint64 * 16)()
+    st = (C.c_uint64 * 16)(*[t] * 16)
+    L.p2_aes_state_sub_bytes(b._h, 777, st, out)          # no such table: must return, not abort
+    assert L.p2_last_error()
