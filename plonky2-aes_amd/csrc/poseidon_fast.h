@@ -65,10 +65,70 @@ GL_HD u64 red128(u64 hi, u64 lo) {
 #endif
     return ((u64)r1 << 32) | r0;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- single-instruction helpers for the multiply-reduce below.  What tools/microbench/valu_rates.hip measures on gfx950
+// (cycles per wave-instruction per SIMD): plain two-source 32-bit ALU ops 2.3; EVERYTHING else -- v_mad_u64_u32,
+// add/sub with carry, v_cndmask, v_cmp, three-source ops, v_lshl_add_u64 -- 4.1.  So a v_mad_u64_u32 is a 64-bit adder
+// with a free multiplier and a carry-out, and the sequences below are built from it.
+// A wave-wide carry lives in an SGPR pair (`sg`).  gfx950 needs two wait states between a VALU write of an SGPR and a
+// VALU read of it, and the compiler's hazard recogniser does not look inside inline asm: every helper that READS a carry
+// starts with s_nop 1 (a nop only delays its own wave; the SIMD issues from the other resident waves meanwhile).
+typedef unsigned long long sg;
+__device__ __forceinline__ u64 mad_co(u32 a, u32 b, u64 c, sg& k) {  // a * b + c, carry-out in k
+    u64 r;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(k) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ u64 mad_eps_co(u32 a, u64 c, sg& k) {  // a * (2^32 - 1) + c, carry-out in k
+    u64 r;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r), "=s"(k) : "v"(a), "v"(c));
+    return r;
+}
+__device__ __forceinline__ u32 subb_co(u32 x, u32 y, sg cin, sg& cout) {  // x - y - cin, borrow-out in cout
+    u32 r;
+    asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r), "=s"(cout) : "v"(x), "v"(y), "s"(cin));
+    return r;
+}
+__device__ __forceinline__ u32 subb0_co(u32 x, sg cin, sg& cout) {  // x - cin, borrow-out in cout
+    u32 r;
+    asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(cout) : "v"(x), "s"(cin));
+    return r;
+}
+__device__ __forceinline__ u32 ones_where(sg m) {  // 0xFFFFFFFF in the lanes of m, else 0
+    u32 r;
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(r) : "s"(m));
+    return r;
+}
+#endif
+
+// a * b mod p as some u64 (a, b arbitrary u64).  Device form, 10 long + 4 short issue slots (the textbook
+// product-then-reduce128 compiles to 15 + 6):
+//   P = a0 b0;  Y = a0 b1 + P.hi;  Y = a1 b0 + Y (carry k);  H = a1 b1 + Y.hi      exact: lo = (P.lo, Y.lo), hi = H + k 2^32
+//   R = lo + H.lo (2^32 - 1)   (carry C)       -- 2^64 = 2^32 - 1: one mad
+//   R = R - H.hi - k           (borrow B)      -- 2^96 = -1; k rides in as the borrow-in
+//   R += (C - B)(2^32 - 1)                     -- C - B in {-1, 0, 1}; neither correction can wrap again (see red128)
 GL_HD u64 mulr(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 P = (u64)a0 * b0;
+    u64 Y = (u64)a0 * b1 + (P >> 32);
+    sg k, C, b1_, B;
+    Y = mad_co(a1, b0, Y, k);
+    const u64 H = (u64)a1 * b1 + (Y >> 32);
+    const u64 lo = (Y << 32) | (u32)P;
+    const u64 R = mad_eps_co((u32)H, lo, C);
+    const u32 r0 = subb_co((u32)R, (u32)(H >> 32), k, b1_);
+    const u32 r1 = subb0_co((u32)(R >> 32), b1_, B);
+    const u32 dh = ones_where(B & ~C);            // - (2^32 - 1) = + {1, 0xFFFFFFFF}
+    const u32 dl = ones_where(C & ~B) - dh;       // + (2^32 - 1) = + {0xFFFFFFFF, 0}
+    u64 d = ((u64)dh << 32) | dl;
+    asm("" : "+v"(d));                            // keep the correction one 64-bit operand: one v_lshl_add_u64, not two
+    return (((u64)r1 << 32) | r0) + d;
+#else
     u64 hi, lo;
     mul128(a, b, hi, lo);
     return red128(hi, lo);
+#endif
 }
 // a arbitrary u64, c canonical (< p): cannot overflow twice
 GL_HD u64 add_canon(u64 a, u64 c) {
@@ -141,7 +201,54 @@ struct Acc {
     }
 };
 
-GL_HD void mds_full(u64* s) {
+// a arbitrary u64, c canonical (< p) -> some u64 congruent to a + c.  The wrap is folded back as + EPS, which cannot
+// wrap again (a + c - 2^64 < c <= p - 1).  Carry chains only: a 64-bit compare-and-select costs a v_cmp_*_u64 plus two
+// v_cndmask_b32 on VCC, and tools/microbench/valu_rates.hip measures the latter at 23 cycles each on gfx950.
+GL_HD u64 add_wrap(u64 a, u64 c) {
+    u32 k, K, b, b2;
+    const u32 lo = __builtin_addc((u32)a, (u32)c, 0u, &k);
+    const u32 hi = __builtin_addc((u32)(a >> 32), (u32)(c >> 32), k, &K);
+    // + K * (2^32 - 1):  lo - K, hi + K - borrow
+    u32 r0 = __builtin_subc(lo, 0u, K, &b);
+    u32 r1 = __builtin_addc(hi, 0u, K, &b2);
+    r1 -= b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(r0), "+v"(r1));  // value barrier, see red128
+#endif
+    return ((u64)r1 << 32) | r0;
+}
+
+// value = al + 2^32 * ah with al, ah < 2^43 (sums of at most 13 products of a 32-bit half with a coefficient < 2^6, plus
+// a 32-bit half of a round constant)  ->  some u64 congruent to it.
+//   ah' = ah + (al >> 32);  value = x0 + 2^32 x1 + 2^64 x2  with x0 = lo32(al), (x1, x2) = halves of ah', x2 < 2^12
+//   = {x1:x0} + x2 * (2^32 - 1): ONE v_mad_u64_u32 (the 64-bit add rides on the multiply; a 32-bit add-with-carry costs
+//   the same issue time as the whole mad, valu_rates.hip), and its carry-out -- possible only when x1 >= 2^32 - 2^12 --
+//   is folded back by a second mad, which cannot wrap (the wrapped sum is < 2^44).
+GL_HD u64 fold_al_ah(u64 al, u64 ah) {
+    const u64 ah2 = ah + (al >> 32);
+    const u32 x2 = (u32)(ah2 >> 32);
+    const u64 base = (ah2 << 32) | (u32)al;
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 r;
+    u32 cv;
+    unsigned long long sc, sc2;
+    asm("v_mad_u64_u32 %[r], %[sc], %[x2], -1, %[base]\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e64 %[cv], %[sc], 0, 0, %[sc]\n\t"
+        "v_mad_u64_u32 %[r], %[sc2], %[cv], -1, %[r]"
+        : [r] "=&v"(r), [cv] "=&v"(cv), [sc] "=&s"(sc), [sc2] "=&s"(sc2)
+        : [x2] "v"(x2), [base] "v"(base));
+    return r;
+#else
+    const u64 t = base + (u64)x2 * gl::EPS;
+    return t < base ? t + gl::EPS : t;
+#endif
+}
+
+// MDS layer of a full round, with the NEXT round's constants folded into the accumulators (rc == nullptr: none):
+//   out[r] = rc[r] + sum_i circ[i] * s[(i + r) % 12] + 8 * s[0] (r == 0)      as some u64 representative.
+// Evaluated on 32-bit halves: every accumulator stays below 2^43, one fold per output word.
+GL_HD void mds_full(u64* s, const unsigned long long* rc) {
     const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     u64 lo[12], hi[12], out[12];
 #pragma unroll
@@ -151,7 +258,7 @@ GL_HD void mds_full(u64* s) {
     }
 #pragma unroll
     for (int r = 0; r < 12; r++) {
-        u64 al = 0, ah = 0;
+        u64 al = rc ? (u64)(u32)rc[r] : 0, ah = rc ? (u64)(rc[r] >> 32) : 0;
 #pragma unroll
         for (int i = 0; i < 12; i++) {
             int j = (i + r) % 12;
@@ -162,18 +269,34 @@ GL_HD void mds_full(u64* s) {
             al += lo[0] * 8;
             ah += hi[0] * 8;
         }
-        u64 l = al + (ah << 32);
-        u64 h = (ah >> 32) + (l < al ? 1 : 0);
-        out[r] = red128(h, l);
+        out[r] = fold_al_ah(al, ah);
     }
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = out[i];
 }
 
-GL_HD void full_round(u64* s, const unsigned long long* rc) {
+// One full round on a state that already carries this round's constants: S-box, then MDS + next constants.
+GL_HD void full_round(u64* s, const unsigned long long* rc_next) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = sbox7(add_canon(s[i], rc[i]));
-    mds_full(s);
+    for (int i = 0; i < 12; i++) s[i] = sbox7(s[i]);
+    mds_full(s, rc_next);
+}
+
+// (ph, pl) = a * b + c exactly (a, b, c arbitrary u64; the sum fits 128 bits).  The addend rides on the multiply-adds:
+// c's low half joins a0*b0, its high half joins a1*b0 -- neither sum can exceed 64 bits.
+GL_HD void mul128_add(u64 a, u64 b, u64 c, u64& hi, u64& lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 p00 = (u64)a0 * b0 + (u32)c;
+    u64 mid = (u64)a0 * b1 + (p00 >> 32);
+    u64 mid2 = (u64)a1 * b0 + ((u64)(u32)mid + (c >> 32));
+    lo = (mid2 << 32) | (u32)p00;
+    hi = (u64)a1 * b1 + (mid >> 32) + (mid2 >> 32);
+#else
+    unsigned __int128 m = (unsigned __int128)a * b + c;
+    lo = (u64)m;
+    hi = (u64)(m >> 64);
+#endif
 }
 
 // In: canonical or not; out: canonical.
@@ -183,7 +306,16 @@ GL_HD void poseidon(u64* s) {
 #else
     const unsigned long long* RC = (const unsigned long long*)gl::H_POSEIDON_RC;
 #endif
-    for (int r = 0; r < 4; r++) full_round(s, RC + 12 * r);
+    // Round constants are never added on their own (except the very first ones): each layer's linear step starts its
+    // accumulators from the constants of the layer that follows.
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = add_wrap(s[i], RC[i]);
+    for (int r = 0; r < 3; r++) full_round(s, RC + 12 * (r + 1));
+    {
+        // 4th full round: next is the partial-round block, whose first S-box input is s0 + a_0; lanes 1.. get nothing
+        unsigned long long nxt[12] = {PF_A[0], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        full_round(s, nxt);
+    }
     {  // dense 11x11 on s[1..], once
         u64 t[11];
         for (int r = 0; r < 11; r++) {
@@ -197,27 +329,25 @@ GL_HD void poseidon(u64* s) {
         for (int r = 0; r < 11; r++) s[1 + r] = t[r];
     }
     for (int i = 0; i < 22; i++) {
-        u64 s0 = sbox7(add_canon(s[0], PF_A[i]));
+        u64 s0 = sbox7(s[0]);
         Acc a;
         a.init();
+        a.e01 = i < 21 ? PF_A[i + 1] : PF_RC26[0];  // the next S-box's / next full round's constant for lane 0
         a.fma(25, s0);
 #pragma unroll
         for (int j = 0; j < 11; j++) a.fma(PF_WHAT[i * 11 + j], s[1 + j]);
 #pragma unroll
         for (int j = 0; j < 11; j++) {
             u64 ph, pl;
-            mul128(PF_V[i * 11 + j], s0, ph, pl);
-            u32 k0, k1, k2;  // (ph, pl) += s[1 + j] as one carry chain (a u64 compare for the carry costs more)
-            const u32 a0 = __builtin_addc((u32)pl, (u32)s[1 + j], 0u, &k0);
-            const u32 a1 = __builtin_addc((u32)(pl >> 32), (u32)(s[1 + j] >> 32), k0, &k1);
-            const u32 a2 = __builtin_addc((u32)ph, 0u, k1, &k2);
-            const u32 a3 = (u32)(ph >> 32) + k2;
-            s[1 + j] = red128(((u64)a3 << 32) | a2, ((u64)a1 << 32) | a0);
+            mul128_add(PF_V[i * 11 + j], s0, s[1 + j], ph, pl);
+            s[1 + j] = red128(ph, pl);
         }
         s[0] = a.reduce();
     }
-    full_round(s, PF_RC26);
-    for (int r = 27; r < 30; r++) full_round(s, RC + 12 * r);
+#pragma unroll
+    for (int j = 1; j < 12; j++) s[j] = add_wrap(s[j], PF_RC26[j]);
+    for (int r = 26; r < 29; r++) full_round(s, RC + 12 * (r + 1));
+    full_round(s, nullptr);
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = canon(s[i]);
 }

@@ -486,10 +486,10 @@ def test_non_canonical_input_value_fails_its_witness(gpu):
 
 
 def test_options_change_scheduling_not_proofs(gpu):
-    data, pws = circuits.mix_columns(gpu, circuits.random_states(9, 5))
+    data, pws = circuits.mix_columns(gpu, circuits.random_states(5, 9))
     base, st = data.prove_batch(pws)
     assert st == [0] * 9
-    data2, _ = circuits.mix_columns(gpu, circuits.random_states(9, 5))
+    data2, _ = circuits.mix_columns(gpu, circuits.random_states(5, 9))
     data2.set_option("chunk", 4)
     data2.set_option("streams", 1)
     got, st2 = data2.prove_batch(pws)
