@@ -282,20 +282,29 @@ GL_HD void full_round(u64* s, const unsigned long long* rc_next) {
     mds_full(s, rc_next);
 }
 
-// (ph, pl) = a * b + c exactly (a, b, c arbitrary u64; the sum fits 128 bits).  The addend rides on the multiply-adds:
-// c's low half joins a0*b0, its high half joins a1*b0 -- neither sum can exceed 64 bits.
-GL_HD void mul128_add(u64 a, u64 b, u64 c, u64& hi, u64& lo) {
+// a * b + c mod p as some u64 (a, b, c arbitrary u64): mulr with the addend riding on the multiply-adds -- c's low half
+// joins a0 b0, its high half joins a0 b1 + P.hi (neither sum can exceed 64 bits: (2^32-1)^2 + 2 (2^32-1) = 2^64 - 1).
+GL_HD u64 mulr_add(u64 a, u64 b, u64 c) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    u64 p00 = (u64)a0 * b0 + (u32)c;
-    u64 mid = (u64)a0 * b1 + (p00 >> 32);
-    u64 mid2 = (u64)a1 * b0 + ((u64)(u32)mid + (c >> 32));
-    lo = (mid2 << 32) | (u32)p00;
-    hi = (u64)a1 * b1 + (mid >> 32) + (mid2 >> 32);
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 P = (u64)a0 * b0 + (u32)c;
+    u64 Y = (u64)a0 * b1 + (P >> 32);
+    Y += c >> 32;
+    sg k, C, b1_, B;
+    Y = mad_co(a1, b0, Y, k);
+    const u64 H = (u64)a1 * b1 + (Y >> 32);
+    const u64 lo = (Y << 32) | (u32)P;
+    const u64 R = mad_eps_co((u32)H, lo, C);
+    const u32 r0 = subb_co((u32)R, (u32)(H >> 32), k, b1_);
+    const u32 r1 = subb0_co((u32)(R >> 32), b1_, B);
+    const u32 dh = ones_where(B & ~C);
+    const u32 dl = ones_where(C & ~B) - dh;
+    u64 d = ((u64)dh << 32) | dl;
+    asm("" : "+v"(d));
+    return (((u64)r1 << 32) | r0) + d;
 #else
     unsigned __int128 m = (unsigned __int128)a * b + c;
-    lo = (u64)m;
-    hi = (u64)(m >> 64);
+    return red128((u64)(m >> 64), (u64)m);
 #endif
 }
 
@@ -338,9 +347,7 @@ GL_HD void poseidon(u64* s) {
         for (int j = 0; j < 11; j++) a.fma(PF_WHAT[i * 11 + j], s[1 + j]);
 #pragma unroll
         for (int j = 0; j < 11; j++) {
-            u64 ph, pl;
-            mul128_add(PF_V[i * 11 + j], s0, s[1 + j], ph, pl);
-            s[1 + j] = red128(ph, pl);
+            s[1 + j] = mulr_add(PF_V[i * 11 + j], s0, s[1 + j]);
         }
         s[0] = a.reduce();
     }
