@@ -31,13 +31,111 @@ static const u64 MULT_GEN = 14293326489335486720ULL;
 static const u64 POW2_GEN = 7277203076849721926ULL;  // order 2^32
 static const u64 W_EXT = 7;                          // x^2 = 7
 
+// ---- device building blocks (gfx950).  tools/microbench/valu_rates.hip measures, in cycles per wave-instruction per
+// SIMD: plain two-source 32-bit ALU ops 2.3; EVERYTHING else -- v_mad_u64_u32, add/sub with carry, v_cndmask, v_cmp,
+// three-source ops, v_lshl_add_u64 -- 4.1 (and v_cndmask_b32 on VCC 23).  So a v_mad_u64_u32 is a 64-bit adder with a free
+// multiplier and a carry-out, and the field operations below are built from it rather than from compare-and-select.
+// A wave-wide carry lives in an SGPR pair (`sg`).  gfx950 needs two wait states between a VALU write of an SGPR and a
+// VALU read of it, and the compiler's hazard recogniser does not look inside inline asm: every helper that READS a carry
+// starts with s_nop 1 (a nop delays only its own wave; the SIMD issues from the other resident waves meanwhile).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned long long sg;
+GL_D u64 mad_co(u32 a, u32 b, u64 c, sg& k) {  // a * b + c, carry-out in k
+    u64 r;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(k) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+GL_D u64 mad_eps_co(u32 a, u64 c, sg& k) {  // a * (2^32 - 1) + c, carry-out in k
+    u64 r;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r), "=s"(k) : "v"(a), "v"(c));
+    return r;
+}
+GL_D u64 add_eps_co(u64 c, sg& k) {  // c + (2^32 - 1) = c - p (mod 2^64); carry-out k <=> c >= p
+    u64 r;
+    asm("v_mad_u64_u32 %0, %1, 1, -1, %2" : "=v"(r), "=s"(k) : "v"(c));
+    return r;
+}
+GL_D u32 sub_co(u32 x, u32 y, sg& cout) {  // x - y, borrow-out in cout
+    u32 r;
+    asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(cout) : "v"(x), "v"(y));
+    return r;
+}
+GL_D u32 subb_co(u32 x, u32 y, sg cin, sg& cout) {  // x - y - cin, borrow-out in cout
+    u32 r;
+    asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r), "=s"(cout) : "v"(x), "v"(y), "s"(cin));
+    return r;
+}
+GL_D u32 subb0_co(u32 x, sg cin, sg& cout) {  // x - cin, borrow-out in cout
+    u32 r;
+    asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(cout) : "v"(x), "s"(cin));
+    return r;
+}
+GL_D u32 ones_where(sg m) {  // 0xFFFFFFFF in the lanes of m, else 0
+    u32 r;
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(r) : "s"(m));
+    return r;
+}
+GL_D u32 pick(sg m, u32 yes, u32 no) {  // per lane: m ? yes : no
+    u32 r;
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(no), "v"(yes), "s"(m));
+    return r;
+}
+// a * b + c mod p as SOME u64 (a, b, c arbitrary u64), 11 long + ~6 short issue slots (the textbook product followed by
+// reduce128 compiles to 15 + 6 without the addend):
+//   P = a0 b0 + c.lo;  Y = a0 b1 + P.hi + c.hi;  Y = a1 b0 + Y (carry k);  H = a1 b1 + Y.hi
+//        exact: lo = (P.lo, Y.lo), hi = H + k 2^32; no intermediate can exceed 64 bits ((2^32-1)^2 + 2 (2^32-1) = 2^64 - 1)
+//   R = lo + H.lo (2^32 - 1)   (carry C)       -- 2^64 = 2^32 - 1: one mad
+//   R = R - H.hi - k           (borrow B)      -- 2^96 = -1; k rides in as the borrow-in
+//   R += (C - B)(2^32 - 1)                     -- C - B in {-1, 0, 1}; neither correction can wrap again: after a carry
+//        R < (2^32-1)^2, so R - H.hi - k + 2^32 - 1 < 2^64; after a borrow alone R >= 2^64 - 2^32, so R - (2^32 - 1) > 0
+template <bool HAS_ADDEND>
+GL_D u64 mulr_add_dev(u64 a, u64 b, u64 c) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 P = HAS_ADDEND ? (u64)a0 * b0 + (u32)c : (u64)a0 * b0;
+    u64 Y = (u64)a0 * b1 + (P >> 32);
+    if (HAS_ADDEND) Y += c >> 32;
+    sg k, C, b1_, B;
+    Y = mad_co(a1, b0, Y, k);
+    const u64 H = (u64)a1 * b1 + (Y >> 32);
+    const u64 lo = (Y << 32) | (u32)P;
+    const u64 R = mad_eps_co((u32)H, lo, C);
+    const u32 r0 = subb_co((u32)R, (u32)(H >> 32), k, b1_);
+    const u32 r1 = subb0_co((u32)(R >> 32), b1_, B);
+    const u32 dh = ones_where(B & ~C);            // - (2^32 - 1) = + {1, 0xFFFFFFFF}
+    const u32 dl = ones_where(C & ~B) - dh;       // + (2^32 - 1) = + {0xFFFFFFFF, 0}
+    u64 d = ((u64)dh << 32) | dl;
+    asm("" : "+v"(d));                            // keep the correction one 64-bit operand: one v_lshl_add_u64, not two
+    return (((u64)r1 << 32) | r0) + d;
+}
+// any u64 -> the canonical representative: r - p = r + (2^32 - 1) (mod 2^64), and that add carries exactly when r >= p
+GL_D u64 canon_dev(u64 r) {
+    sg c;
+    const u64 t = add_eps_co(r, c);
+    return ((u64)pick(c, (u32)(t >> 32), (u32)(r >> 32)) << 32) | pick(c, (u32)t, (u32)r);
+}
+#endif
+
 GL_HD u64 add(u64 a, u64 b) {
     u64 s = a + b;
     // a,b < p so a+b < 2p < 2^65; overflow or s>=p => subtract p once.
     if (s < a || s >= P) s -= P;
     return s;
 }
-GL_HD u64 sub(u64 a, u64 b) { return a >= b ? a - b : a + (P - b); }
+GL_HD u64 sub(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // a - b, and on a borrow - (2^32 - 1) = + {1, 0xFFFFFFFF} (the wrapped difference is 2^64 too large): 4 long slots
+    sg b0, B;
+    const u32 d0 = sub_co((u32)a, (u32)b, b0);
+    const u32 d1 = subb_co((u32)(a >> 32), (u32)(b >> 32), b0, B);
+    const u32 e = ones_where(B);
+    u64 fix = ((u64)e << 32) | (0u - e);
+    asm("" : "+v"(fix));
+    return (((u64)d1 << 32) | d0) + fix;
+#else
+    return a >= b ? a - b : a + (P - b);
+#endif
+}
+GL_HD u64 sub_ref(u64 a, u64 b) { return a >= b ? a - b : a + (P - b); }  // textbook form (self-tests)
 GL_HD u64 neg(u64 a) { return a ? P - a : 0; }
 GL_HD u64 dbl(u64 a) { return add(a, a); }
 
@@ -63,14 +161,27 @@ GL_HD u64 reduce128(u64 hi, u64 lo) {
     if (r >= P) r -= P;
     return r;
 }
-GL_HD u64 mul(u64 a, u64 b) {
+GL_HD u64 mul_ref(u64 a, u64 b) {  // textbook form: the host path, and what the device self-test checks mul against
     u64 hi, lo;
     mul64(a, b, hi, lo);
     return reduce128(hi, lo);
 }
+GL_HD u64 mul(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return canon_dev(mulr_add_dev<false>(a, b, 0));
+#else
+    return mul_ref(a, b);
+#endif
+}
 GL_HD u64 sqr(u64 a) { return mul(a, a); }
 // a*b + c
-GL_HD u64 mul_add(u64 a, u64 b, u64 c) { return add(mul(a, b), c); }
+GL_HD u64 mul_add(u64 a, u64 b, u64 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return canon_dev(mulr_add_dev<true>(a, b, c));
+#else
+    return add(mul(a, b), c);
+#endif
+}
 
 GL_HD u64 pow(u64 b, u64 e) {
     u64 r = 1;

@@ -65,65 +65,10 @@ GL_HD u64 red128(u64 hi, u64 lo) {
 #endif
     return ((u64)r1 << 32) | r0;
 }
-#if defined(__HIP_DEVICE_COMPILE__)
-// ---- single-instruction helpers for the multiply-reduce below.  What tools/microbench/valu_rates.hip measures on gfx950
-// (cycles per wave-instruction per SIMD): plain two-source 32-bit ALU ops 2.3; EVERYTHING else -- v_mad_u64_u32,
-// add/sub with carry, v_cndmask, v_cmp, three-source ops, v_lshl_add_u64 -- 4.1.  So a v_mad_u64_u32 is a 64-bit adder
-// with a free multiplier and a carry-out, and the sequences below are built from it.
-// A wave-wide carry lives in an SGPR pair (`sg`).  gfx950 needs two wait states between a VALU write of an SGPR and a
-// VALU read of it, and the compiler's hazard recogniser does not look inside inline asm: every helper that READS a carry
-// starts with s_nop 1 (a nop only delays its own wave; the SIMD issues from the other resident waves meanwhile).
-typedef unsigned long long sg;
-__device__ __forceinline__ u64 mad_co(u32 a, u32 b, u64 c, sg& k) {  // a * b + c, carry-out in k
-    u64 r;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(k) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ u64 mad_eps_co(u32 a, u64 c, sg& k) {  // a * (2^32 - 1) + c, carry-out in k
-    u64 r;
-    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r), "=s"(k) : "v"(a), "v"(c));
-    return r;
-}
-__device__ __forceinline__ u32 subb_co(u32 x, u32 y, sg cin, sg& cout) {  // x - y - cin, borrow-out in cout
-    u32 r;
-    asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r), "=s"(cout) : "v"(x), "v"(y), "s"(cin));
-    return r;
-}
-__device__ __forceinline__ u32 subb0_co(u32 x, sg cin, sg& cout) {  // x - cin, borrow-out in cout
-    u32 r;
-    asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(cout) : "v"(x), "s"(cin));
-    return r;
-}
-__device__ __forceinline__ u32 ones_where(sg m) {  // 0xFFFFFFFF in the lanes of m, else 0
-    u32 r;
-    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(r) : "s"(m));
-    return r;
-}
-#endif
-
-// a * b mod p as some u64 (a, b arbitrary u64).  Device form, 10 long + 4 short issue slots (the textbook
-// product-then-reduce128 compiles to 15 + 6):
-//   P = a0 b0;  Y = a0 b1 + P.hi;  Y = a1 b0 + Y (carry k);  H = a1 b1 + Y.hi      exact: lo = (P.lo, Y.lo), hi = H + k 2^32
-//   R = lo + H.lo (2^32 - 1)   (carry C)       -- 2^64 = 2^32 - 1: one mad
-//   R = R - H.hi - k           (borrow B)      -- 2^96 = -1; k rides in as the borrow-in
-//   R += (C - B)(2^32 - 1)                     -- C - B in {-1, 0, 1}; neither correction can wrap again (see red128)
+// a * b mod p as some u64 (a, b arbitrary u64): gl::mulr_add_dev on the device (see gl.h for the sequence).
 GL_HD u64 mulr(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    const u64 P = (u64)a0 * b0;
-    u64 Y = (u64)a0 * b1 + (P >> 32);
-    sg k, C, b1_, B;
-    Y = mad_co(a1, b0, Y, k);
-    const u64 H = (u64)a1 * b1 + (Y >> 32);
-    const u64 lo = (Y << 32) | (u32)P;
-    const u64 R = mad_eps_co((u32)H, lo, C);
-    const u32 r0 = subb_co((u32)R, (u32)(H >> 32), k, b1_);
-    const u32 r1 = subb0_co((u32)(R >> 32), b1_, B);
-    const u32 dh = ones_where(B & ~C);            // - (2^32 - 1) = + {1, 0xFFFFFFFF}
-    const u32 dl = ones_where(C & ~B) - dh;       // + (2^32 - 1) = + {0xFFFFFFFF, 0}
-    u64 d = ((u64)dh << 32) | dl;
-    asm("" : "+v"(d));                            // keep the correction one 64-bit operand: one v_lshl_add_u64, not two
-    return (((u64)r1 << 32) | r0) + d;
+    return gl::mulr_add_dev<false>(a, b, 0);
 #else
     u64 hi, lo;
     mul128(a, b, hi, lo);
@@ -136,7 +81,13 @@ GL_HD u64 add_canon(u64 a, u64 c) {
     if (r < a) r += gl::EPS;
     return r;
 }
-GL_HD u64 canon(u64 a) { return a >= gl::P ? a - gl::P : a; }
+GL_HD u64 canon(u64 a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return gl::canon_dev(a);
+#else
+    return a >= gl::P ? a - gl::P : a;
+#endif
+}
 GL_HD u64 sbox7(u64 x) {
     u64 x2 = mulr(x, x), x3 = mulr(x2, x), x4 = mulr(x2, x2);
     return mulr(x3, x4);
@@ -282,26 +233,10 @@ GL_HD void full_round(u64* s, const unsigned long long* rc_next) {
     mds_full(s, rc_next);
 }
 
-// a * b + c mod p as some u64 (a, b, c arbitrary u64): mulr with the addend riding on the multiply-adds -- c's low half
-// joins a0 b0, its high half joins a0 b1 + P.hi (neither sum can exceed 64 bits: (2^32-1)^2 + 2 (2^32-1) = 2^64 - 1).
+// a * b + c mod p as some u64 (a, b, c arbitrary u64): the addend rides on the multiply-adds (gl.h)
 GL_HD u64 mulr_add(u64 a, u64 b, u64 c) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    const u64 P = (u64)a0 * b0 + (u32)c;
-    u64 Y = (u64)a0 * b1 + (P >> 32);
-    Y += c >> 32;
-    sg k, C, b1_, B;
-    Y = mad_co(a1, b0, Y, k);
-    const u64 H = (u64)a1 * b1 + (Y >> 32);
-    const u64 lo = (Y << 32) | (u32)P;
-    const u64 R = mad_eps_co((u32)H, lo, C);
-    const u32 r0 = subb_co((u32)R, (u32)(H >> 32), k, b1_);
-    const u32 r1 = subb0_co((u32)(R >> 32), b1_, B);
-    const u32 dh = ones_where(B & ~C);
-    const u32 dl = ones_where(C & ~B) - dh;
-    u64 d = ((u64)dh << 32) | dl;
-    asm("" : "+v"(d));
-    return (((u64)r1 << 32) | r0) + d;
+    return gl::mulr_add_dev<true>(a, b, c);
 #else
     unsigned __int128 m = (unsigned __int128)a * b + c;
     return red128((u64)(m >> 64), (u64)m);

@@ -1403,6 +1403,13 @@ __global__ void k_selftest(unsigned long long* bad, u64 seed, size_t threads) {
         const u32 c0 = __builtin_addc((u32)r, 0xFFFFFFFFu, 0u, &k);
         const u32 c1 = __builtin_addc((u32)(r >> 32), 0u, k, &K);
         if ((K ? (((u64)c1 << 32) | c0) : r) != want) b++;
+        // the mad-based field operations every kernel uses (gl.h) against the textbook forms
+        const u64 x = hi % gl::P, y = lo % gl::P, z = rnd() % gl::P;
+        if (gl::mul(x, y) != gl::mul_ref(x, y)) b++;
+        if (gl::mul(hi, lo) != gl::mul_ref(x, y)) b++;  // non-canonical inputs are fine for mul
+        if (gl::sub(x, y) != gl::sub_ref(x, y) || gl::sub(y, x) != gl::sub_ref(y, x)) b++;
+        if (gl::mul_add(x, y, z) != gl::add(gl::mul_ref(x, y), z)) b++;
+        if (glf::canon(hi) != hi % gl::P) b++;
     }
     u64 s0[12], s1[12];
     for (int k = 0; k < 12; k++) {

@@ -523,12 +523,12 @@ def test_same_blob_on_every_visible_device(gpu):
     ndev = gpu.lib().p2_gpu_device_count()
     data0, pws = circuits.mix_columns(gpu, circuits.random_states(3, 4))
     ref, st = data0.prove_batch(pws)
-    assert st == [0] * 3
+    assert st == [0] * len(pws)
     for dev in range(ndev):
         d = gpu.CircuitData(data0.blob, device=dev)
         assert d.verifier_data() == data0.verifier_data()
         got, st = d.prove_batch(pws)
-        assert st == [0] * 3 and got == ref
+        assert st == [0] * len(pws) and got == ref
     with pytest.raises(gpu.P2Error):
         gpu.CircuitData(data0.blob, device=ndev).gpu()
 
