@@ -18,6 +18,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILE_TAG = "r02"     # profiles/<tag>_traffic.json (PMC bytes) and profiles/<tag>_valu.json (PMC VALU instructions) of this round
+NUM_SIMD, LANES_PER_CYCLE = 256 * 4, 32  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles
 
 
 def splitmix64(seed):
@@ -115,8 +117,9 @@ def main():
     ap.add_argument("--plaintext-bytes", type=int, default=1024)
     ap.add_argument("--workload", choices=["aes-gcm", "elgamal"], default="aes-gcm",
                     help="aes-gcm = BASELINE.json's metric workload (default); elgamal = configs[3]'s circuit")
+    ap.add_argument("--pcie-steps", type=int, default=2, help="extra untimed-for-`value` steps through the host path (value_pcie_inclusive); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=5, help="proofs timed on the host for cpu_baseline (median, after one warm-up)")
+    ap.add_argument("--cpu-sample", type=int, default=3, help="proofs timed on the host for cpu_baseline (median, after one warm-up)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD torch.distributed.run (never an
@@ -228,8 +231,31 @@ def main():
         dt = float(t.item())
     assert int(status.abs().sum().item()) == 0
 
+    # PCIe-inclusive rate (never `value`): the same batch through p2_prove_batch -- host assignments in, proof bytes out,
+    # via the handle's pinned staging buffers -- the shape of the reference's `data.prove(pw)` returning bytes to the host
+    pcie = None
+    if rank == 0 and args.pcie_steps > 0:
+        asg = (pkg.api._Assignment * B)()
+        keep = []
+        for i, pw in enumerate(pws):
+            ts, vs = (C.c_uint64 * nt)(*pw.map.keys()), (C.c_uint64 * nt)(*pw.map.values())
+            keep.append((ts, vs))
+            asg[i].targets, asg[i].values, asg[i].count = ts, vs, nt
+        hbuf = C.create_string_buffer(B * pb)
+        hstat = (C.c_int * B)()
+        assert lib.p2_prove_batch(h, B, asg, hbuf, hstat) == 0, lib.p2_last_error()   # warm-up: staging buffers are allocated here
+        t1 = time.perf_counter()
+        for _ in range(args.pcie_steps):
+            assert lib.p2_prove_batch(h, B, asg, hbuf, hstat) == 0, lib.p2_last_error()
+        pdt = time.perf_counter() - t1
+        assert not any(hstat)
+        assert hbuf.raw[:pb] == bytes(proofs[:pb].cpu().numpy().tobytes()), "host-path proof differs from the device-path proof"
+        pcie = {"value": round(B * args.pcie_steps / pdt, 3), "unit": "proofs/s", "steps": args.pcie_steps,
+                "note": "p2_prove_batch: host assignments in, proof bytes out (pinned staging, async copies); calls are synchronous, so consecutive batches do not overlap"}
+
     # per-kernel launch durations, measured live with HIP events on the proving stream (separate, untimed pass)
     roofline = None
+    roofline_valu = None
     kernels = {}
     if rank == 0:
         lib.p2_circuit_set_timing(h, 1)
@@ -256,7 +282,7 @@ def main():
         avg_ms = ms / cnt
         traffic = None
         try:  # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x2 per calibration, WRITE_SIZE), profiles/
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_traffic.json")))
             key = {"hash_leaves": "k_hash_leaves", "lde": "k_ntt_lds", "quotient": "k_quotient<false>"}.get(dom)
             if key and L == 1024 and chunk == tj.get("chunk") and args.workload == "aes-gcm":
                 ent = tj["per_launch_avg_bytes"][key]
@@ -270,6 +296,26 @@ def main():
                         "share_of_gpu_time": round(ms / total, 3),
                         "note": "kernel is VALU-issue bound (a Poseidon permutation is ~27k v_add-equivalent issue slots), not HBM bound; see DESIGN.md section 5",
                         "poseidon_perm_per_s": round((24 * (8 << info["degree_bits"]) * chunk / 3.0) / (avg_ms * 1e-3)) if dom == "hash_leaves" else None}
+        # The roofline that actually bounds the path: VALU issue.  Instruction counts per launch are a property of the
+        # kernel and the workload (rocprofv3 --pmc SQ_INSTS_VALU, profiles/<tag>_valu.json via tools/pmc_valu.py); the
+        # duration is this run's own HIP-event measurement; the clock is the one the chip held in the counter pass.
+        try:
+            vj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_valu.json")))["kernels"]
+            key = {"hash_leaves": "k_hash_leaves", "lde": "k_ntt_lds", "quotient": "k_quotient<false>"}.get(dom)
+            if key in vj and L == 1024 and args.workload == "aes-gcm" and chunk == 128:
+                e = vj[key]
+                clock = e["clock_GHz"] * 1e9
+                ach = e["valu_insts"] * 64 / (avg_ms * 1e-3)
+                peak = NUM_SIMD * LANES_PER_CYCLE * clock
+                perms = 24 * (8 << info["degree_bits"]) * chunk / 3.0
+                roofline_valu = {"bound": "valu_issue", "kernel": dom, "achieved": round(ach / 1e12, 2), "peak": round(peak / 1e12, 2), "unit": "T lane-ops/s",
+                                 "frac": round(ach / peak, 4), "clock_GHz": e["clock_GHz"], "valu_insts_per_launch": e["valu_insts"],
+                                 "insts_per_perm": round(e["valu_insts"] * 64 / perms) if dom == "hash_leaves" else None,
+                                 "cycles_per_inst": round(NUM_SIMD * clock * avg_ms * 1e-3 / e["valu_insts"], 3),
+                                 "note": "peak = 256 CU x 4 SIMD x 32 lanes x clock (one wave64 instruction per 2 cycles); tools/microbench/valu_rates.hip measures 2.3 cycles for "
+                                         "plain two-source ops and 4.1 for v_mad_u64_u32 / carry / select / three-source ops, so this instruction mix cannot exceed ~0.6"}
+        except Exception:  # noqa: BLE001
+            roofline_valu = None
 
     cpu_baseline = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -285,8 +331,19 @@ def main():
         cdt = sorted(times)[len(times) // 2] * args.cpu_sample  # median proof time
         got = bytes(proofs[: args.cpu_sample * pb].cpu().numpy().tobytes())
         assert got[(args.cpu_sample - 1) * pb: args.cpu_sample * pb] == ref, "GPU proof differs from the oracle's"
-        cpu_baseline = {"value": round(args.cpu_sample / cdt, 4), "unit": "proofs/s", "cores": oracle_lib.lib().orc_num_threads(),
-                        "kind": "port", "sample": "median of %d proofs after 1 warm-up, same workload (%s; C++ restatement, OpenMP; not the Rust reference)" % (args.cpu_sample, label.split(" (")[0])}
+        stages = {k: round(v, 4) for k, v in oracle_lib.OracleCircuit.last_stage_seconds().items()}  # of the last proof timed
+        cores = oracle_lib.lib().orc_num_threads()
+        # thread scaling: ONE proof on one thread (BASELINE.md asks for the core count used and how the port scales)
+        oracle_lib.lib().orc_set_num_threads(1)
+        t1 = time.perf_counter()
+        st, _ = oc.prove(pws[0].map)
+        one = time.perf_counter() - t1
+        stages1 = {k: round(v, 4) for k, v in oracle_lib.OracleCircuit.last_stage_seconds().items()}
+        oracle_lib.lib().orc_set_num_threads(cores)
+        cpu_baseline = {"value": round(args.cpu_sample / cdt, 4), "unit": "proofs/s", "cores": cores,
+                        "kind": "port", "sample": "median of %d proofs after 1 warm-up, same workload (%s; C++ restatement, OpenMP; not the Rust reference)" % (args.cpu_sample, label.split(" (")[0]),
+                        "stage_seconds": stages, "single_thread": {"value": round(1.0 / one, 4), "unit": "proofs/s", "stage_seconds": stages1,
+                                                                   "speedup_of_all_cores": round(one * args.cpu_sample / cdt, 2)}}
 
     if rank == 0:
         total_proofs = B * args.steps * world
@@ -299,7 +356,8 @@ def main():
             "n_gpus": world, "ranks_seen": dist.get_world_size() if dist else 1, "devices": devices, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks field)", "data": "synthetic",
             "config": {"workload": label, "proofs_per_step_per_gpu": B, "proof_bytes": pb, "parallelism": "independent proofs sharded by index"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu_baseline,
+            "value_pcie_inclusive": pcie,
             "whole_path": whole_path,
             "chunk_proofs": chunk if rank == 0 else None, "kernels_ms_per_chunk": {k: round(v[0], 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1][0])},
         }

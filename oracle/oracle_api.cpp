@@ -79,6 +79,11 @@ size_t orc_verifier_data(void* hp, uint64_t* out, size_t cap) {
     if (out && cap >= v.size()) memcpy(out, v.data(), v.size() * 8);
     return v.size();
 }
+// seconds the last orc_prove on this thread spent per stage: witness, commitments, partial products + lookups, quotient,
+// openings, FRI (see StageClock in oracle_prover.h)
+void orc_last_stage_seconds(double* out6) {
+    for (int i = 0; i < 6; i++) out6[i] = g_stage_seconds[i];
+}
 // status: 0 ok, 1 witness conflict / lookup miss, 2 missing input, 3 zeta in subgroup, -1 buffer too small
 int orc_prove(void* hp, const uint64_t* targets, const uint64_t* values, size_t n_in, uint8_t* out, size_t out_cap, size_t* out_len, int want_trace) {
     Handle* h = (Handle*)hp;

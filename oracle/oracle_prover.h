@@ -12,6 +12,7 @@
 //   * fri_proof_of_work uses rayon find_any: here the SMALLEST satisfying witness is taken.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <string>
 
@@ -127,6 +128,19 @@ struct OCircuit {
 
 typedef std::map<std::string, std::vector<u64>> Trace;
 
+// Wall-clock seconds the last prove() spent per stage (bench.py's cpu_baseline breakdown): 0 witness generation,
+// 1 commitments (iFFT + coset FFT + Merkle trees of the wires / Z / quotient oracles), 2 partial products + lookup
+// polynomials, 3 quotient evaluation, 4 openings, 5 FRI (batch combination, commit phase, PoW, queries, serialisation).
+static thread_local double g_stage_seconds[6];
+static inline double now_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct StageClock {
+    double t = now_seconds();
+    void lap(int stage) {
+        double u = now_seconds();
+        g_stage_seconds[stage] += u - t;
+        t = u;
+    }
+};
 // oracle_index 0 = constants|sigmas (never blinded); 1 wires, 2 zs/partial products/lookups, 3 quotient
 static inline void commit_from_coeffs(const OCircuit& C, Batch& b, int oracle_index) {
     size_t n = C.n, N = n << C.cfg.rate_bits, cols = b.cols;
@@ -551,8 +565,11 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
         return f;
     };
     // 1. witness
+    for (double& v : g_stage_seconds) v = 0;
+    StageClock clk;
     std::vector<std::vector<u64>> wires;
     int st = generate_witness(C, in_targets, in_values, n_in, wires);
+    clk.lap(0);
     if (st) return st;
     if (trace) {
         std::vector<u64> f;
@@ -561,7 +578,9 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
     }
     // 2. wires commitment
     Batch wb;
+    clk.lap(0);
     commit_from_values(C, wb, wires, 1);
+    clk.lap(1);
     tr("wires_cap", flat_cap(wb.tree));
     // 3. challenger
     Challenger chal;
@@ -654,7 +673,9 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
         tr("zs", f);
     }
     Batch zb;
+    clk.lap(2);
     commit_from_values(C, zb, zcols, 2);
+    clk.lap(1);
     tr("zs_cap", flat_cap(zb.tree));
     chal.observe_cap(zb.tree.cap());
     for (size_t i = 0; i < NC; i++) ch.alphas.push_back(chal.challenge());
@@ -707,7 +728,9 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
             for (auto& c : qb.coeffs) f.insert(f.end(), c.begin(), c.end());
             tr("quotient_coeffs", f);
         }
+        clk.lap(3);
         commit_from_coeffs(C, qb, 3);
+        clk.lap(1);
     }
     tr("quotient_cap", flat_cap(qb.tree));
     chal.observe_cap(qb.tree.cap());
@@ -752,6 +775,7 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
         tr("openings", f);
     }
     // 10. FRI: batch polynomials (PolynomialBatch::prove_openings)
+    clk.lap(4);
     X2 fri_alpha = chal.ext_challenge();
     tr("fri_alpha", {fri_alpha.c0, fri_alpha.c1});
     struct PolyRef {
@@ -905,6 +929,7 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
     for (auto& e : coeffs) w.ext(e);
     w.w64(pow_witness);
     proof.swap(w.b);
+    clk.lap(5);
     return 0;
 }
 

@@ -48,6 +48,7 @@ def lib():
         L.orc_ghash.argtypes = [C.c_char_p, C.c_char_p, sz, C.c_char_p]
         L.orc_gctr.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, sz, C.c_char_p]
         L.orc_gcm_encrypt.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, sz, C.c_char_p, C.c_char_p]
+        L.orc_last_stage_seconds.argtypes = [C.POINTER(C.c_double)]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         _lib = L
@@ -113,6 +114,12 @@ class OracleCircuit:
         out = (C.c_uint64 * cap)()
         st = lib().orc_generate_witness(self.h, ts, vs, len(pw_map), out)
         return st, (list(out) if st == 0 else None)
+
+    @staticmethod
+    def last_stage_seconds():
+        out = (C.c_double * 6)()
+        lib().orc_last_stage_seconds(out)
+        return dict(zip(("witness", "commitments", "partial_products_lookups", "quotient", "openings", "fri"), out))
 
     def trace(self, name):
         n = lib().orc_trace_len(self.h, name.encode())
