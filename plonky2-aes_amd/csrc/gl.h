@@ -55,6 +55,16 @@ GL_D u64 add_eps_co(u64 c, sg& k) {  // c + (2^32 - 1) = c - p (mod 2^64); carry
     asm("v_mad_u64_u32 %0, %1, 1, -1, %2" : "=v"(r), "=s"(k) : "v"(c));
     return r;
 }
+GL_D u32 add_co(u32 x, u32 y, sg& cout) {  // x + y, carry-out in cout
+    u32 r;
+    asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(cout) : "v"(x), "v"(y));
+    return r;
+}
+GL_D u32 addc_co(u32 x, u32 y, sg cin, sg& cout) {  // x + y + cin, carry-out in cout
+    u32 r;
+    asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r), "=s"(cout) : "v"(x), "v"(y), "s"(cin));
+    return r;
+}
 GL_D u32 sub_co(u32 x, u32 y, sg& cout) {  // x - y, borrow-out in cout
     u32 r;
     asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(cout) : "v"(x), "v"(y));
@@ -116,8 +126,24 @@ GL_D u64 canon_dev(u64 r) {
 #endif
 
 GL_HD u64 add(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // s = a + b (carry c1); t = s - p = s + (2^32 - 1) (carry c2 <=> s >= p); the sum needs the subtraction iff c1 | c2.
+    // 5 long issue slots; the compare-and-select form compiles to 7.
+    sg k, c1, c2;
+    const u32 s0 = add_co((u32)a, (u32)b, k);
+    const u32 s1 = addc_co((u32)(a >> 32), (u32)(b >> 32), k, c1);
+    const u64 t = add_eps_co(((u64)s1 << 32) | s0, c2);
+    const sg m = c1 | c2;
+    return ((u64)pick(m, (u32)(t >> 32), s1) << 32) | pick(m, (u32)t, s0);
+#else
     u64 s = a + b;
     // a,b < p so a+b < 2p < 2^65; overflow or s>=p => subtract p once.
+    if (s < a || s >= P) s -= P;
+    return s;
+#endif
+}
+GL_HD u64 add_ref(u64 a, u64 b) {  // textbook form (self-tests)
+    u64 s = a + b;
     if (s < a || s >= P) s -= P;
     return s;
 }

@@ -195,6 +195,129 @@ __global__ __launch_bounds__(1024) void k_ntt_lds(NttArgs a) {
     }
 }
 
+// ---- register-blocked transform (2^8 <= n <= 2^14): n / 16 threads, every thread owns 16 points.
+// The same decimation-in-frequency butterflies as k_ntt_lds, regrouped so that FOUR stages run in registers between two
+// trips through LDS: with h the half-size of a stage, the 16 points {base + t' + r M : r < 16} (M = stride, t' < M) are
+// closed under the stages h = 8M, 4M, 2M, M.  n = 2^14 takes 2 + 4 + 4 + 4 stages: the first step comes straight from the
+// global loads (x[t + (n/16) k] is both the coalesced load pattern and the M = n/16 layout), three more steps exchange
+// through LDS, a last trip puts the data in store order -- 4 barriers and 4 LDS round trips where k_ntt_lds needs 8 and 7,
+// and 16 loads + 15 twiddle loads in flight per thread instead of 4 + 3.  rocprofv3 showed k_ntt_lds at 7.3 SIMD-cycles
+// per VALU instruction (profiles/r02_valu.json): it waits on barriers and dependent loads, not on arithmetic.
+// LDS index i is stored at i + (i >> 4): a thread's 16 consecutive points (last step, M = 1) and the 16-element sub-blocks
+// of the M = 16 step then fall on distinct banks.
+__device__ __forceinline__ u32 ntt_pad(u32 i) { return i + (i >> 4); }
+// stages `first`..3 of a step with stride 2^m on the 16 points x[r] (r <-> index base + t' + r * 2^m)
+template <int A>
+__device__ __forceinline__ void ntt_r16_stage(u64* x, const u64* __restrict__ tw, u32 tp, int m, int tw_log /*log2 of the table order*/) {
+    constexpr int half = 8 >> A;
+    // h = 2^(m + 3 - A); twiddle of pair (r, r + half): w_{2h}^(t' + 2^m (r mod half)) = table[(t' + 2^m (r mod half)) << (tw_log - (m + 4 - A))]
+    const int sh = tw_log - (m + 4 - A);
+    u64 w[half];
+#pragma unroll
+    for (int j = 0; j < half; j++) w[j] = tw[(size_t)(tp + ((u32)j << m)) << sh];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        if (r & half) continue;
+        const u64 u = x[r], v = x[r + half];
+        x[r] = gl::add(u, v);
+        x[r + half] = gl::mul(gl::sub(u, v), w[r % half]);
+    }
+}
+// SPLIT: one workgroup transforms HALF a column -- the first stage (h = n/2) is done while loading (every workgroup reads
+// both halves and keeps the sums or the twiddled differences), the remaining n/2-point transform runs in 70 KiB of LDS, so
+// that two workgroups share a compute unit and the load / store phases of one overlap the butterflies of the other.  (One
+// 139 KiB workgroup per compute unit leaves the SIMDs idle while its waves wait on memory: a wave's own prefetch cannot
+// help, vmcnt retires in order.)  Natural-order input and bit-reversed output only (the LDE), which is where the time is.
+template <bool SPLIT>
+__global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
+    extern __shared__ __align__(16) u64 lds[];
+    const int logn = SPLIT ? a.logn - 1 : a.logn;  // size of the transform this workgroup runs in LDS
+    const u32 n = 1u << logn, T = n >> 4, t = threadIdx.x;
+    const u32 unit = SPLIT ? blockIdx.x >> 1 : blockIdx.x, half = SPLIT ? (blockIdx.x & 1) : 0;
+    const u32 col = unit / a.cosets, coset = unit % a.cosets;
+    const u32 blk = a.block_of_coset[coset];
+    const size_t full = (size_t)1 << a.logn;
+    const u64* in = a.in + (size_t)blockIdx.y * a.in_batch_stride + (size_t)col * a.in_col_stride + (a.in_coset_blocks ? (size_t)blk * full : 0);
+    u64* out = a.out + (size_t)blockIdx.y * a.out_batch_stride + (size_t)col * a.out_col_stride + (size_t)blk * full + (size_t)half * n;
+    const u64* pre = a.pre ? a.pre + (size_t)coset * full : nullptr;
+    const u64* post = a.post ? a.post + (size_t)coset * full : nullptr;
+    u64 x[16];
+    if (SPLIT) {
+        // stage h = n_full / 2 on the fly: sums feed the first half of the (bit-reversed) output, differences the second
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u32 i = t + T * k;
+            u64 u = in[i], v = in[i + n];
+            if (pre) {
+                u = gl::mul(u, pre[i]);
+                v = gl::mul(v, pre[i + n]);
+            }
+            x[k] = half ? gl::mul(gl::sub(u, v), a.tw[(size_t)i << (a.log_nmax - a.logn)]) : gl::add(u, v);
+        }
+    } else if (a.bitrev_in) {
+        // position i holds natural index rev(i): coalesced read, permute through LDS
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u32 i = t + T * k, dst = __brev(i) >> (32 - logn);
+            u64 v = in[i];
+            if (pre) v = gl::mul(v, pre[dst]);
+            lds[ntt_pad(dst)] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = lds[ntt_pad(t + T * k)];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = in[t + T * k];
+        if (pre) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = gl::mul(x[k], pre[t + T * k]);
+        }
+    }
+    // first step: the leading rem = logn mod 4 (or 4) stages on the whole array, stride M = n / 16
+    // (with M = n / 16 stage A has h = n / 2^(A+1): these ARE the first `rem` stages of the whole transform)
+    const int rem = (logn & 3) ? (logn & 3) : 4;
+    {
+        const int m = logn - 4;
+        ntt_r16_stage<0>(x, a.tw, t, m, a.log_nmax);
+        if (rem >= 2) ntt_r16_stage<1>(x, a.tw, t, m, a.log_nmax);
+        if (rem >= 3) ntt_r16_stage<2>(x, a.tw, t, m, a.log_nmax);
+        if (rem >= 4) ntt_r16_stage<3>(x, a.tw, t, m, a.log_nmax);
+    }
+    u32 base_idx = t, stride = T;  // the thread's 16 points are base_idx + stride * r
+    for (int logN = logn - rem; logN >= 4; logN -= 4) {
+        // exchange: write the points back where they live, read the next step's 16
+#pragma unroll
+        for (int r = 0; r < 16; r++) lds[ntt_pad(base_idx + stride * r)] = x[r];
+        __syncthreads();
+        const int m = logN - 4;
+        const u32 tp = t & ((1u << m) - 1);
+        base_idx = ((t >> m) << logN) | tp;
+        stride = 1u << m;
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = lds[ntt_pad(base_idx + stride * r)];
+        // no barrier here: a thread writes back exactly the 16 locations it read, nobody else touches them in this step
+        ntt_r16_stage<0>(x, a.tw, tp, m, a.log_nmax);
+        ntt_r16_stage<1>(x, a.tw, tp, m, a.log_nmax);
+        ntt_r16_stage<2>(x, a.tw, tp, m, a.log_nmax);
+        ntt_r16_stage<3>(x, a.tw, tp, m, a.log_nmax);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) lds[ntt_pad(base_idx + stride * r)] = x[r];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 i = t + T * k;
+        const u32 src = (!SPLIT && a.bitrev_out) ? (__brev(i) >> (32 - logn)) : i;
+        u64 v = lds[ntt_pad(src)];
+        if (post)
+            v = gl::mul(v, post[(size_t)half * n + i]);
+        else if (a.post_scalar != 1)
+            v = gl::mul(v, a.post_scalar);
+        out[i] = v;
+    }
+}
+
 // ---- large transforms (n > 2^14): four-step split n = n1 * n2.  Pass 1 (this kernel): for a tile of T adjacent
 // columns j2, the n1-point DIF over the stride-n2 elements x[j1*n2 + j2], then the twiddle w_n^(j2*k1); the result
 // for k1 lands in row rev(k1).  Pass 2 is k_ntt_lds on the n1 contiguous rows of n2 points.  Together: natural

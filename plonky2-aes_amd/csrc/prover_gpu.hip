@@ -155,9 +155,20 @@ static int upload(p2_circuit* C, T** p, const T* host, size_t count) {
 static inline dim3 g1(size_t work, u32 block, u32 y = 1, u32 z = 1) { return dim3((u32)((work + block - 1) / block), y, z); }
 
 // ---------------------------------------------------------------------------------- building blocks
+static const u32 R16_MIN_BITS = 8;  // the register-blocked kernel needs n / 16 threads >= a few waves; smaller transforms keep k_ntt_lds
+static size_t r16_lds_bytes(int logn) { return 8 * (((size_t)1 << logn) + ((size_t)1 << (logn - 4))); }
 static int run_ntt(p2_circuit* C, const char* name, NttArgs a, u32 cols, u32 batch) {
-    size_t shmem = (size_t)8 << a.logn;
     a.log_nmax = (int)C->logn;
+    if ((u32)a.logn >= 13 && !a.bitrev_in && !a.bitrev_out && !a.post) {
+        // half a column per workgroup: two (or more) workgroups per compute unit overlap each other's memory phases
+        LAUNCH(C, name, k_ntt_r16<true>, dim3(2 * cols * a.cosets, batch), dim3(1u << (a.logn - 5)), r16_lds_bytes(a.logn - 1), a);
+        return 0;
+    }
+    if ((u32)a.logn >= R16_MIN_BITS) {
+        LAUNCH(C, name, k_ntt_r16<false>, dim3(cols * a.cosets, batch), dim3(1u << (a.logn - 4)), r16_lds_bytes(a.logn), a);
+        return 0;
+    }
+    size_t shmem = (size_t)8 << a.logn;
     LAUNCH(C, name, k_ntt_lds, dim3(cols * a.cosets, batch), dim3(1024), shmem, a);
     return 0;
 }
@@ -200,7 +211,7 @@ static int ntt_big(p2_circuit* C, const char* name, const u64* in, u64* out, con
     b.cosets = 1;
     size_t rows = ((size_t)cols * cosets) << log_n1;
     // grid.x is limited to 2^31-1; rows*1 fits for every supported size
-    LAUNCH(C, name, k_ntt_lds, dim3((u32)rows, batch), dim3(1024), (size_t)8 << log_n2, b);
+    LAUNCH(C, name, k_ntt_r16<false>, dim3((u32)rows, batch), dim3(1u << (log_n2 - 4)), r16_lds_bytes((int)log_n2), b);
     return 0;
 }
 // values [cols][n] -> coeffs [cols][n].  `scratch` ([cols][n] per proof, same batch stride) is needed when n > 2^14.
@@ -1021,8 +1032,10 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
         if (hipSetDevice(device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
         if (hipStreamCreate(&C->stream) != hipSuccess) throw std::runtime_error("hipStreamCreate failed");
         if (hipEventCreateWithFlags(&C->ev_witness, hipEventDisableTiming) != hipSuccess) throw std::runtime_error("hipEventCreate failed");
-        if (hipFuncSetAttribute((const void*)k_ntt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
-            throw std::runtime_error("cannot raise the dynamic LDS limit to 128 KiB");
+        if (hipFuncSetAttribute((const void*)k_ntt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_ntt_r16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r16_lds_bytes(14)) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_ntt_r16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r16_lds_bytes(13)) != hipSuccess)
+            throw std::runtime_error("cannot raise the dynamic LDS limit for the NTT kernels");
         if (hipFuncSetAttribute((const void*)k_ntt_pass1, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
             throw std::runtime_error("cannot set the dynamic LDS limit of the pass-1 NTT");
         // opening maps
@@ -1408,7 +1421,8 @@ __global__ void k_selftest(unsigned long long* bad, u64 seed, size_t threads) {
         if (gl::mul(x, y) != gl::mul_ref(x, y)) b++;
         if (gl::mul(hi, lo) != gl::mul_ref(x, y)) b++;  // non-canonical inputs are fine for mul
         if (gl::sub(x, y) != gl::sub_ref(x, y) || gl::sub(y, x) != gl::sub_ref(y, x)) b++;
-        if (gl::mul_add(x, y, z) != gl::add(gl::mul_ref(x, y), z)) b++;
+        if (gl::mul_add(x, y, z) != gl::add_ref(gl::mul_ref(x, y), z)) b++;
+        if (gl::add(x, y) != gl::add_ref(x, y) || gl::add(x, gl::P - 1) != gl::add_ref(x, gl::P - 1) || gl::add(y, gl::P - 1 - (y & 1)) != gl::add_ref(y, gl::P - 1 - (y & 1))) b++;
         if (glf::canon(hi) != hi % gl::P) b++;
     }
     u64 s0[12], s1[12];
@@ -1459,6 +1473,8 @@ struct PrimCtx {
         C.N = C.n << 3;
         HIPCHECK(hipStreamCreate(&C.stream));
         HIPCHECK(hipFuncSetAttribute((const void*)k_ntt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void*)k_ntt_r16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r16_lds_bytes(14)));
+        HIPCHECK(hipFuncSetAttribute((const void*)k_ntt_r16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r16_lds_bytes(13)));
         size_t n = C.n;
         std::vector<u64> twf(n), twi(n);
         u64 w = gl::root_of_unity(degree_bits), wi = gl::inv(w), x = 1, xi = 1;
