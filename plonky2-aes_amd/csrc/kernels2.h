@@ -58,9 +58,10 @@ struct AlphaAcc {
 
 // One thread per point of the LDE coset (bit-reversed position p); evaluates every constraint of
 // eval_vanishing_poly_base (term k is weighted by alpha^k, k in plonky2's order [Z(1) | partial products | lookups |
-// gates]) for both challenges at once and divides by Z_H.  Every wire / sigma value is loaded once per view
-// (permutation argument, LookupTableGate view, LookupGate view, gate constraints): the first version re-read the
-// columns per challenge and per constraint family and fetched 3.8x its algorithmic bytes (profiles/r01_traffic.json).
+// gates]) for both challenges at once and divides by Z_H.  The 80 wire columns are walked TWICE: once for the permutation
+// argument with the ArithmeticGate constraints riding along (a chunk of 8 wires is exactly two arithmetic ops), once for the
+// LookupTableGate and LookupGate views together (6 columns = 2 table slots + 3 looking slots).  Round 1 walked them once per
+// view (4x) and fetched 2.3x its algorithmic bytes (profiles/r01_traffic.json; the very first version 3.8x).
 template <bool HAS_POSEIDON>
 __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
     const u32 N = a.n << a.rate_bits;
@@ -83,6 +84,22 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
     // term index bases
     const u32 idx_pp = a.NC, nlk = a.nlp ? 4 + a.num_luts + 2 * a.nsldc : 0;
     const u32 idx_lk = idx_pp + a.NC * (a.npp + 1), idx_gate = idx_lk + a.NC * nlk;
+    // gate filters (needed early: the arithmetic constraints ride on the permutation argument's walk over the wires)
+    const u64* gc = C + (size_t)(a.nsel + a.nls) * N;
+    const u64 c0 = gc[0], c1 = gc[(size_t)1 * N];
+    u64 f_arith = 0, f_const = 0, f_pi = 0, f_pos = 0;
+    for (u32 g = 0; g < a.num_gates; g++) {
+        u32 kind = a.gate_kind[g];
+        if (kind != p2::G_ARITHMETIC && kind != p2::G_CONSTANT && kind != p2::G_PUBLIC_INPUT && kind != p2::G_POSEIDON) continue;
+        u64 s = C[(size_t)a.gate_sel[g] * N], filter = 1;
+        for (u32 j = a.group_lo[g]; j < a.group_hi[g]; j++)
+            if (j != g) filter = gl::mul(filter, gl::sub(j, s));
+        if (a.nsel > 1) filter = gl::mul(filter, gl::sub(p2::UNUSED_SELECTOR, s));
+        if (kind == p2::G_ARITHMETIC) f_arith = filter;
+        if (kind == p2::G_CONSTANT) f_const = filter;
+        if (kind == p2::G_PUBLIC_INPUT) f_pi = filter;
+        if (kind == p2::G_POSEIDON) f_pos = filter;
+    }
     for (u32 i = 0; i < a.NC; i++) A.add(i, gl::mul(l0, gl::sub(Zs[(size_t)i * N], 1)));
     {  // permutation argument, both challenges per loaded wire
         const u64 b0 = cw[CH_BETAS], b1 = cw[CH_BETAS + 1], g0 = cw[CH_GAMMAS], g1 = cw[CH_GAMMAS + 1];
@@ -90,12 +107,21 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
         for (u32 chunk = 0; chunk <= a.npp; chunk++) {
             u64 num0 = 1, den0 = 1, num1 = 1, den1 = 1;
             u32 j1 = min(a.R, (chunk + 1) * a.qdf);
+            u64 w8[8];
             for (u32 j = chunk * a.qdf; j < j1; j++) {
                 const u64 wv = W[(size_t)j * N], sg = S[(size_t)j * N], kj = a.k_is[j];
+                if (!HAS_POSEIDON) w8[(j - chunk * a.qdf) & 7] = wv;
                 num0 = gl::mul(num0, gl::add(gl::add(wv, gl::mul(bx0, kj)), g0));
                 den0 = gl::mul(den0, gl::add(gl::add(wv, gl::mul(b0, sg)), g0));
                 num1 = gl::mul(num1, gl::add(gl::add(wv, gl::mul(bx1, kj)), g1));
                 den1 = gl::mul(den1, gl::add(gl::add(wv, gl::mul(b1, sg)), g1));
+            }
+            if (!HAS_POSEIDON && f_arith && a.qdf == 8) {
+                // ArithmeticGate ops 2*chunk and 2*chunk + 1 occupy exactly these 8 wires: out - (c0 m0 m1 + c1 addend)
+                for (u32 h = 0; h < 2; h++) {
+                    const u64 m0 = w8[4 * h], m1 = w8[4 * h + 1], ad = w8[4 * h + 2], o = w8[4 * h + 3];
+                    A.add(idx_gate + 2 * chunk + h, gl::mul(f_arith, gl::sub(o, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1)))));
+                }
             }
             for (u32 i = 0; i < 2; i++) {
                 u64 prev = chunk == 0 ? Zs[(size_t)i * N] : Zs[(size_t)(a.NC + i * a.npp + chunk - 1) * N];
@@ -127,80 +153,72 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
             for (u32 l = 0; l < a.num_luts; l++) A.add(t0 + 3 + l, gl::mul(sel[(size_t)(4 + l) * N], gl::sub(z_re, zv[a.lut_last_row[l]])));
             cur[i] = lzn[i][0];
         }
-        // LookupTableGate view: slots (inp, out, mult); RE Horner and the Sum transition of each partial poly
+        // LookupTableGate view (slots (inp, out, mult): RE Horner and the Sum transition of each partial poly) and
+        // LookupGate view (slots (inp, out): the LDC transition of each partial poly) in ONE walk over the wire columns:
+        // six columns are two table slots and three looking slots (round 1 walked the columns once per view).
         {
-            u64 prod[2] = {1, 1}, sum[2] = {0, 0};
-            u32 poly = 0, in_poly = 0;
-            for (u32 s_ = 0; s_ < p2::LUT_SLOTS; s_++) {
-                const u64 win = W[(size_t)(3 * s_) * N], wout = W[(size_t)(3 * s_ + 1) * N], wm = W[(size_t)(3 * s_ + 2) * N];
+            u64 tprod[2] = {1, 1}, tsum[2] = {0, 0}, lprod[2] = {1, 1}, lsum[2] = {0, 0};
+            u32 tpoly = 0, tin = 0, lpoly = 0, lin = 0;
+            const u32 lu_deg = a.qdf - 1;
+            auto lut_slot = [&](u32 s_, u64 win, u64 wout, u64 wm) {
                 for (u32 i = 0; i < 2; i++) {
                     cur[i] = gl::add(gl::mul(cur[i], dD[i]), gl::add(win, gl::mul(dB[i], wout)));
                     const u64 f = gl::sub(dAl[i], gl::add(win, gl::mul(dA[i], wout)));
-                    sum[i] = gl::add(gl::mul(sum[i], f), gl::mul(wm, prod[i]));  // sum' = sum*f + mult*prod
-                    prod[i] = gl::mul(prod[i], f);
+                    tsum[i] = gl::add(gl::mul(tsum[i], f), gl::mul(wm, tprod[i]));  // sum' = sum*f + mult*prod
+                    tprod[i] = gl::mul(tprod[i], f);
                 }
-                if (++in_poly == a.lut_deg || s_ + 1 == p2::LUT_SLOTS) {
+                if (++tin == a.lut_deg || s_ + 1 == p2::LUT_SLOTS) {
                     for (u32 i = 0; i < 2; i++) {
-                        u64 prev = poly == 0 ? lzn[i][(size_t)a.nsldc * N] : lz[i][(size_t)poly * N];
-                        u64 diff = gl::sub(lz[i][(size_t)(1 + poly) * N], prev);
-                        A.add(idx_lk + i * nlk + 4 + a.num_luts + 2 * poly, gl::mul(s_sre, gl::sub(gl::mul(prod[i], diff), sum[i])));
-                        prod[i] = 1;
-                        sum[i] = 0;
+                        u64 prev = tpoly == 0 ? lzn[i][(size_t)a.nsldc * N] : lz[i][(size_t)tpoly * N];
+                        u64 diff = gl::sub(lz[i][(size_t)(1 + tpoly) * N], prev);
+                        A.add(idx_lk + i * nlk + 4 + a.num_luts + 2 * tpoly, gl::mul(s_sre, gl::sub(gl::mul(tprod[i], diff), tsum[i])));
+                        tprod[i] = 1;
+                        tsum[i] = 0;
                     }
-                    poly++;
-                    in_poly = 0;
+                    tpoly++;
+                    tin = 0;
                 }
-            }
-            for (u32 i = 0; i < 2; i++) A.add(idx_lk + i * nlk + 3 + a.num_luts, gl::mul(s_sre, gl::sub(lz[i][0], cur[i])));
-        }
-        // LookupGate view: slots (inp, out); the LDC transition of each partial poly
-        {
-            u64 prod[2] = {1, 1}, sum[2] = {0, 0};
-            u32 poly = 0, in_poly = 0;
-            const u32 lu_deg = a.qdf - 1;
-            for (u32 s_ = 0; s_ < p2::LU_SLOTS; s_++) {
-                const u64 win = W[(size_t)(2 * s_) * N], wout = W[(size_t)(2 * s_ + 1) * N];
+            };
+            auto lu_slot = [&](u32 s_, u64 win, u64 wout) {
                 for (u32 i = 0; i < 2; i++) {
                     const u64 f = gl::sub(dAl[i], gl::add(win, gl::mul(dA[i], wout)));
-                    sum[i] = gl::add(gl::mul(sum[i], f), prod[i]);
-                    prod[i] = gl::mul(prod[i], f);
+                    lsum[i] = gl::add(gl::mul(lsum[i], f), lprod[i]);
+                    lprod[i] = gl::mul(lprod[i], f);
                 }
-                if (++in_poly == lu_deg || s_ + 1 == p2::LU_SLOTS) {
+                if (++lin == lu_deg || s_ + 1 == p2::LU_SLOTS) {
                     for (u32 i = 0; i < 2; i++) {
-                        u64 prev = poly == 0 ? lzn[i][(size_t)a.nsldc * N] : lz[i][(size_t)poly * N];
-                        u64 diff = gl::sub(lz[i][(size_t)(1 + poly) * N], prev);
-                        A.add(idx_lk + i * nlk + 4 + a.num_luts + 2 * poly + 1, gl::mul(s_ldc, gl::add(gl::mul(prod[i], diff), sum[i])));
-                        prod[i] = 1;
-                        sum[i] = 0;
+                        u64 prev = lpoly == 0 ? lzn[i][(size_t)a.nsldc * N] : lz[i][(size_t)lpoly * N];
+                        u64 diff = gl::sub(lz[i][(size_t)(1 + lpoly) * N], prev);
+                        A.add(idx_lk + i * nlk + 4 + a.num_luts + 2 * lpoly + 1, gl::mul(s_ldc, gl::add(gl::mul(lprod[i], diff), lsum[i])));
+                        lprod[i] = 1;
+                        lsum[i] = 0;
                     }
-                    poly++;
-                    in_poly = 0;
+                    lpoly++;
+                    lin = 0;
                 }
+            };
+            static_assert(p2::LUT_SLOTS == 26 && p2::LU_SLOTS == 40, "the six-column grouping below assumes 26 table slots and 40 looking slots");
+            for (u32 g = 0; g < 13; g++) {
+                u64 w[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) w[k] = W[(size_t)(6 * g + k) * N];
+                lut_slot(2 * g, w[0], w[1], w[2]);
+                lut_slot(2 * g + 1, w[3], w[4], w[5]);
+                lu_slot(3 * g, w[0], w[1]);
+                lu_slot(3 * g + 1, w[2], w[3]);
+                lu_slot(3 * g + 2, w[4], w[5]);
             }
+            lu_slot(39, W[(size_t)78 * N], W[(size_t)79 * N]);
+            for (u32 i = 0; i < 2; i++) A.add(idx_lk + i * nlk + 3 + a.num_luts, gl::mul(s_sre, gl::sub(lz[i][0], cur[i])));
         }
     }
     // gate constraints: constraint slot k collects every gate's k-th constraint times the gate's filter
     {
-        const u64* gc = C + (size_t)(a.nsel + a.nls) * N;
-        const u64 c0 = gc[0], c1 = gc[(size_t)1 * N];
-        u64 f_arith = 0, f_const = 0, f_pi = 0, f_pos = 0;
-        for (u32 g = 0; g < a.num_gates; g++) {
-            u32 kind = a.gate_kind[g];
-            if (kind != p2::G_ARITHMETIC && kind != p2::G_CONSTANT && kind != p2::G_PUBLIC_INPUT && kind != p2::G_POSEIDON) continue;
-            u64 s = C[(size_t)a.gate_sel[g] * N], filter = 1;
-            for (u32 j = a.group_lo[g]; j < a.group_hi[g]; j++)
-                if (j != g) filter = gl::mul(filter, gl::sub(j, s));
-            if (a.nsel > 1) filter = gl::mul(filter, gl::sub(p2::UNUSED_SELECTOR, s));
-            if (kind == p2::G_ARITHMETIC) f_arith = filter;
-            if (kind == p2::G_CONSTANT) f_const = filter;
-            if (kind == p2::G_PUBLIC_INPUT) f_pi = filter;
-            if (kind == p2::G_POSEIDON) f_pos = filter;
-        }
         // k-th constraint of every gate other than PoseidonGate, already multiplied by the gate's filter
         auto other_gates = [&](u32 k) -> u64 {
             u64 term = 0;
             u64 w0 = 0;
-            if (k < p2::ARITH_OPS && f_arith) {
+            if ((HAS_POSEIDON || a.qdf != 8) && k < p2::ARITH_OPS && f_arith) {  // otherwise already added during the permutation walk
                 u64 m0 = W[(size_t)(4 * k) * N], m1 = W[(size_t)(4 * k + 1) * N], ad = W[(size_t)(4 * k + 2) * N], o = W[(size_t)(4 * k + 3) * N];
                 term = gl::mul(f_arith, gl::sub(o, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1))));
             }
@@ -213,7 +231,8 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
             p2::poseidon_gate_constraints<p2::FBase>([&](u32 i) { return W[(size_t)i * N]; },
                                                      [&](int k, u64 cst) { A.add(idx_gate + (u32)k, gl::add(gl::mul(f_pos, cst), other_gates((u32)k))); });
         } else {
-            for (u32 k = 0; k < a.num_gate_constraints; k++) A.add(idx_gate + k, other_gates(k));
+            const u32 kmax = a.qdf == 8 ? min(a.num_gate_constraints, 4u) : a.num_gate_constraints;  // what is left: ConstantGate / PublicInputGate
+            for (u32 k = 0; k < kmax; k++) A.add(idx_gate + k, other_gates(k));
         }
     }
     const u64 zi = a.zh_inv[coset];
