@@ -228,6 +228,12 @@ typedef struct {
  * may call p2_prove_batch / p2_prove_batch_device concurrently on the SAME handle (enqueueing is serialised inside; each
  * caller gets its own staging set) as well as on different handles. */
 int p2_prove_batch(p2_circuit*, size_t batch, const p2_assignment* inputs, uint8_t* proofs, int* status);
+/* The same call sharded over several handles of ONE compiled circuit, normally one handle per HIP device of the node
+ * (p2_circuit_load(blob, len, d) for d = 0..N-1): witness i goes to the handle that owns its contiguous, balanced range of
+ * the batch (the partition of SURVEY.md 8e: independent proofs, no data crosses devices), one host thread per handle.
+ * proofs / status are indexed like the inputs.  P2_ERR_INVALID if the handles are not loads of the same circuit. */
+int p2_prove_batch_multi(p2_circuit* const* handles, size_t n_handles, size_t batch, const p2_assignment* inputs,
+                         uint8_t* proofs, int* status);
 /* Same pipeline with inputs already resident on the device and proofs left on the device:
  * d_values: [batch][n_targets] u64 (device pointer), targets shared by the whole batch (host pointer); the value
  * 2^64-1 (not a field element) marks "this witness does not assign the target".

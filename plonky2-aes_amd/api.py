@@ -74,6 +74,7 @@ def lib():
         "p2_circuit_set_zk_seed": (C.c_int, [vp, u64]),
         "p2_circuit_set_zk_key": (C.c_int, [vp, C.POINTER(u64)]),
         "p2_circuit_set_option": (C.c_int, [vp, C.c_char_p, C.c_long]),
+        "p2_prove_batch_multi": (C.c_int, [C.POINTER(vp), sz, sz, C.POINTER(_Assignment), C.c_char_p, C.POINTER(C.c_int)]),
         "p2_builder_add_virtual_target": (u64, [vp]), "p2_builder_constant": (u64, [vp, u64]),
         "p2_builder_zero": (u64, [vp]), "p2_builder_one": (u64, [vp]),
         "p2_builder_arithmetic": (u64, [vp, u64, u64, u64, u64, u64]),
@@ -422,6 +423,25 @@ class CircuitData:
         if lib().p2_prove_batch(self.gpu(), B, asg, buf, status):
             raise P2Error("p2_prove_batch failed: " + _err())
         pb, base = self.proof_bytes, C.addressof(buf)   # (buf.raw would copy the whole buffer once per proof)
+        return [C.string_at(base + i * pb, pb) if status[i] == 0 else None for i in range(B)], list(status)
+
+    @staticmethod
+    def prove_batch_multi(datas, pws):
+        """One batch sharded over several CircuitData loads of the same blob (one per HIP device): p2_prove_batch_multi."""
+        B = len(pws)
+        asg = (_Assignment * B)()
+        keep = []
+        for i, pw in enumerate(pws):
+            ts, vs = _arr(list(pw.map.keys())), _arr(list(pw.map.values()))
+            keep.append((ts, vs))
+            asg[i].targets, asg[i].values, asg[i].count = ts, vs, len(pw.map)
+        pb = datas[0].proof_bytes
+        buf = C.create_string_buffer(B * pb)
+        status = (C.c_int * B)()
+        hs = (C.c_void_p * len(datas))(*[d.gpu() for d in datas])
+        if lib().p2_prove_batch_multi(hs, len(datas), B, asg, buf, status):
+            raise P2Error("p2_prove_batch_multi failed: " + _err())
+        base = C.addressof(buf)
         return [C.string_at(base + i * pb, pb) if status[i] == 0 else None for i in range(B)], list(status)
 
     def prove_batch_device(self, targets, d_values, d_proofs, d_status, batch, stream=None):

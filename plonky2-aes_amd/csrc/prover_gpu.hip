@@ -9,6 +9,7 @@
 #include <mutex>
 #include <random>
 #include <string>
+#include <thread>
 
 #include "capi_common.h"
 #include "os_random.h"
@@ -1282,6 +1283,33 @@ int p2_prove_batch(p2_circuit* C, size_t batch, const p2_assignment* inputs, uin
             memset(proofs + i * C->pbytes, 0, C->pbytes);
         }
     if (dbg) fprintf(stderr, "[p2aes] pack %.3f enqueue %.3f wait %.3f unpack %.3f s\n", t_b - t_a, t_c - t_b, t_d - t_c, now() - t_d);
+    return P2_OK;
+}
+
+// In-process multi-device form of p2_prove_batch: contiguous balanced ranges of the batch, one host thread per handle.
+int p2_prove_batch_multi(p2_circuit* const* handles, size_t n_handles, size_t batch, const p2_assignment* inputs, uint8_t* proofs, int* status) {
+    if (n_handles == 0 || !handles) return set_error("p2_prove_batch_multi needs at least one handle"), P2_ERR_INVALID;
+    for (size_t h = 0; h < n_handles; h++)
+        if (!handles[h] || handles[h]->pbytes != handles[0]->pbytes || handles[h]->verifier_data != handles[0]->verifier_data)
+            return set_error("p2_prove_batch_multi: the handles are not loads of one compiled circuit"), P2_ERR_INVALID;
+    if (batch == 0) return P2_OK;
+    const size_t pb = handles[0]->pbytes, base = batch / n_handles, extra = batch % n_handles;
+    std::vector<int> rc(n_handles, P2_OK);
+    std::vector<std::string> err(n_handles);
+    std::vector<std::thread> workers;
+    size_t lo = 0;
+    for (size_t h = 0; h < n_handles; h++) {
+        const size_t cnt = base + (h < extra ? 1 : 0), first = lo;
+        lo += cnt;
+        if (cnt == 0) continue;
+        workers.emplace_back([=, &rc, &err] {
+            rc[h] = p2_prove_batch(handles[h], cnt, inputs + first, proofs + first * pb, status + first);
+            if (rc[h] != P2_OK) err[h] = g_last_error;  // the error slot is thread-local: carry it to the caller's thread
+        });
+    }
+    for (auto& w : workers) w.join();
+    for (size_t h = 0; h < n_handles; h++)
+        if (rc[h] != P2_OK) return set_error("handle " + std::to_string(h) + " (device " + std::to_string(handles[h]->device) + "): " + err[h]), rc[h];
     return P2_OK;
 }
 

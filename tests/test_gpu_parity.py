@@ -531,6 +531,20 @@ def test_same_blob_on_every_visible_device(gpu):
         assert st == [0] * len(pws) and got == ref
     with pytest.raises(gpu.P2Error):
         gpu.CircuitData(data0.blob, device=ndev).gpu()
+    # the in-process sharded call: one handle per visible device (and, on a one-GPU box, a second handle on device 0 so that
+    # the partition itself is exercised): same proofs, in input order, including a failing witness in the middle
+    handles = [gpu.CircuitData(data0.blob, device=d) for d in range(ndev)]
+    if ndev == 1:
+        handles.append(gpu.CircuitData(data0.blob, device=0))
+    bad = gpu.PartialWitness()
+    bad.map = dict(pws[1].map)
+    bad.map[list(bad.map)[-1]] ^= 1
+    mixed = [pws[0], bad] + pws[1:]
+    got, st = gpu.CircuitData.prove_batch_multi(handles, mixed)
+    assert st == [0, 1] + [0] * (len(pws) - 1) and got[0] == ref[0] and got[2:] == ref[1:] and got[1] is None
+    other, _ = circuits.gf_2_8_add(gpu, [(1, 2)])
+    with pytest.raises(gpu.P2Error, match="one compiled circuit"):
+        gpu.CircuitData.prove_batch_multi([handles[0], other], mixed)
 
 
 def test_zk_full_width_key_and_os_key(gpu, orc):
