@@ -318,7 +318,7 @@ def main():
             roofline_valu = None
 
     cpu_baseline = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU baseline is reported at N = 1 only
         import oracle_lib  # the checker, used here only as the reported CPU baseline
         oc = oracle_lib.OracleCircuit(data.blob)
         st, ref = oc.prove(pws[0].map)  # warm-up (page faults, OpenMP team start-up)
