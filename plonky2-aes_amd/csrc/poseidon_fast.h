@@ -129,6 +129,24 @@ struct Acc {
         p = (u64)a1 * b0; t = o01 + p; co += t < p; o01 = t;
 #endif
     }
+    // a < 2^32: only the two products with a's low half exist
+    GL_HD void fma_small(u32 a0, u64 b) {
+        u32 b0 = (u32)b, b1 = (u32)(b >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+        unsigned long long s1, s2;
+        asm("v_mad_u64_u32 %[e01], %[s1], %[a0], %[b0], %[e01]\n\t"
+            "v_mad_u64_u32 %[o01], %[s2], %[a0], %[b1], %[o01]\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32_e64 %[ce0], %[s1], 0, %[ce0], %[s1]\n\t"
+            "v_addc_co_u32_e64 %[co], %[s2], 0, %[co], %[s2]"
+            : [e01] "+v"(e01), [o01] "+v"(o01), [ce0] "+v"(ce0), [co] "+v"(co), [s1] "=&s"(s1), [s2] "=&s"(s2)
+            : [a0] "v"(a0), [b0] "v"(b0), [b1] "v"(b1));
+#else
+        u64 p, t;
+        p = (u64)a0 * b0; t = e01 + p; ce0 += t < p; e01 = t;
+        p = (u64)a0 * b1; t = o01 + p; co += t < p; o01 = t;
+#endif
+    }
     // value = e01 + 2^32*o01 + 2^64*(e23 + ce0 + 2^32*co) + 2^128*ce2, summed limb by limb with carry chains (no 64-bit
     // compares), then 2^128 = -2^32 (mod p).  Some u64 congruent to the value; not canonical.
     GL_HD u64 reduce() const {
@@ -226,6 +244,20 @@ GL_HD void mds_full(u64* s, const unsigned long long* rc) {
     for (int i = 0; i < 12; i++) s[i] = out[i];
 }
 
+// Row 0 of the MDS alone: rc + sum_i circ[i] * s[i] + 8 * s[0]
+GL_HD u64 mds_row0(const u64* s, u64 rc) {
+    const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    u64 al = (u32)rc, ah = rc >> 32;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        al += (s[i] & gl::EPS) * C[i];
+        ah += (s[i] >> 32) * C[i];
+    }
+    al += (s[0] & gl::EPS) * 8;
+    ah += (s[0] >> 32) * 8;
+    return fold_al_ah(al, ah);
+}
+
 // One full round on a state that already carries this round's constants: S-box, then MDS + next constants.
 GL_HD void full_round(u64* s, const unsigned long long* rc_next) {
 #pragma unroll
@@ -256,28 +288,27 @@ GL_HD void poseidon(u64* s) {
     for (int i = 0; i < 12; i++) s[i] = add_wrap(s[i], RC[i]);
     for (int r = 0; r < 3; r++) full_round(s, RC + 12 * (r + 1));
     {
-        // 4th full round: next is the partial-round block, whose first S-box input is s0 + a_0; lanes 1.. get nothing
-        unsigned long long nxt[12] = {PF_A[0], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        full_round(s, nxt);
-    }
-    {  // dense 11x11 on s[1..], once
-        u64 t[11];
+        // 4th full round with the dense 11x11 layer of the partial-round block merged into its linear step: lane 0 is the
+        // MDS row (+ a_0, the first partial S-box's constant), lanes 1.. are rows of E = D0 . MDS[1.., :] (gen_poseidon_fast.py)
+        u64 z[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) z[i] = sbox7(s[i]);
+#pragma nounroll
         for (int r = 0; r < 11; r++) {
             Acc a;
             a.init();
 #pragma unroll
-            for (int c = 0; c < 11; c++) a.fma(PF_D0[r * 11 + c], s[1 + c]);
-            t[r] = a.reduce();
+            for (int c = 0; c < 12; c++) a.fma(PF_E[r * 12 + c], z[c]);
+            s[1 + r] = a.reduce();  // straight into the (dead) state: a separate result array costs 34 VGPRs and a wave of occupancy
         }
-#pragma unroll
-        for (int r = 0; r < 11; r++) s[1 + r] = t[r];
+        s[0] = mds_row0(z, PF_A[0]);
     }
     for (int i = 0; i < 22; i++) {
         u64 s0 = sbox7(s[0]);
         Acc a;
         a.init();
         a.e01 = i < 21 ? PF_A[i + 1] : PF_RC26[0];  // the next S-box's / next full round's constant for lane 0
-        a.fma(25, s0);
+        a.fma_small(25, s0);
 #pragma unroll
         for (int j = 0; j < 11; j++) a.fma(PF_WHAT[i * 11 + j], s[1 + j]);
 #pragma unroll
