@@ -50,6 +50,12 @@ GL_D u64 mad_eps_co(u32 a, u64 c, sg& k) {  // a * (2^32 - 1) + c, carry-out in 
     asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r), "=s"(k) : "v"(a), "v"(c));
     return r;
 }
+GL_D u64 add_u32(u64 c, u32 x) {  // c + x through the multiplier (x * 1 + c): one long slot, no zero-extension moves
+    u64 r;
+    sg dead;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(r), "=s"(dead) : "v"(x), "v"(c));
+    return r;
+}
 GL_D u64 add_eps_co(u64 c, sg& k) {  // c + (2^32 - 1) = c - p (mod 2^64); carry-out k <=> c >= p
     u64 r;
     asm("v_mad_u64_u32 %0, %1, 1, -1, %2" : "=v"(r), "=s"(k) : "v"(c));
@@ -103,7 +109,7 @@ GL_D u64 mulr_add_dev(u64 a, u64 b, u64 c) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u64 P = HAS_ADDEND ? (u64)a0 * b0 + (u32)c : (u64)a0 * b0;
     u64 Y = (u64)a0 * b1 + (P >> 32);
-    if (HAS_ADDEND) Y += c >> 32;
+    if (HAS_ADDEND) Y = add_u32(Y, (u32)(c >> 32));
     sg k, C, b1_, B;
     Y = mad_co(a1, b0, Y, k);
     const u64 H = (u64)a1 * b1 + (Y >> 32);
