@@ -206,6 +206,13 @@ __global__ __launch_bounds__(1024) void k_ntt_lds(NttArgs a) {
 // LDS index i is stored at i + (i >> 4): a thread's 16 consecutive points (last step, M = 1) and the 16-element sub-blocks
 // of the M = 16 step then fall on distinct banks.
 __device__ __forceinline__ u32 ntt_pad(u32 i) { return i + (i >> 4); }
+// The 16 points of a thread are base + r * stride with stride = 1 (base a multiple of 16) or stride >= 16: the padded
+// index is affine in r, pad(base) + r * (stride + stride / 16), so one address costs one add instead of five instructions.
+struct NttLdsWalk {
+    u32 a0, step;  // byte address of point 0, byte step between points
+    __device__ __forceinline__ NttLdsWalk(u32 base, u32 stride) : a0(8 * ntt_pad(base)), step(stride >= 16 ? 8 * (stride + (stride >> 4)) : 8 * stride) {}
+    __device__ __forceinline__ u64& at(u64* lds, int r) const { return *(u64*)((char*)lds + (a0 + (u32)r * step)); }
+};
 // stages `first`..3 of a step with stride 2^m on the 16 points x[r] (r <-> index base + t' + r * 2^m)
 template <int A>
 __device__ __forceinline__ void ntt_r16_stage(u64* x, const u64* __restrict__ tw, u32 tp, int m, int tw_log /*log2 of the table order*/) {
@@ -213,8 +220,11 @@ __device__ __forceinline__ void ntt_r16_stage(u64* x, const u64* __restrict__ tw
     // h = 2^(m + 3 - A); twiddle of pair (r, r + half): w_{2h}^(t' + 2^m (r mod half)) = table[(t' + 2^m (r mod half)) << (tw_log - (m + 4 - A))]
     const int sh = tw_log - (m + 4 - A);
     u64 w[half];
+    // 32-bit byte offsets from the uniform table base (the table is at most 2^14 * 8 B): one v_add per twiddle instead
+    // of a 64-bit shift-and-add address each
+    const u32 off0 = tp << (sh + 3), dj = 1u << (m + sh + 3);
 #pragma unroll
-    for (int j = 0; j < half; j++) w[j] = tw[(size_t)(tp + ((u32)j << m)) << sh];
+    for (int j = 0; j < half; j++) w[j] = *(const u64*)((const char*)tw + (off0 + (u32)j * dj));
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         if (r & half) continue;
@@ -264,8 +274,11 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
             lds[ntt_pad(dst)] = v;
         }
         __syncthreads();
+        {
+            const NttLdsWalk w0(t, T);
 #pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = lds[ntt_pad(t + T * k)];
+            for (int k = 0; k < 16; k++) x[k] = w0.at(lds, k);
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = in[t + T * k];
@@ -287,29 +300,38 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
     u32 base_idx = t, stride = T;  // the thread's 16 points are base_idx + stride * r
     for (int logN = logn - rem; logN >= 4; logN -= 4) {
         // exchange: write the points back where they live, read the next step's 16
+        {
+            const NttLdsWalk wr(base_idx, stride);
 #pragma unroll
-        for (int r = 0; r < 16; r++) lds[ntt_pad(base_idx + stride * r)] = x[r];
+            for (int r = 0; r < 16; r++) wr.at(lds, r) = x[r];
+        }
         __syncthreads();
         const int m = logN - 4;
         const u32 tp = t & ((1u << m) - 1);
         base_idx = ((t >> m) << logN) | tp;
         stride = 1u << m;
+        {
+            const NttLdsWalk rd(base_idx, stride);
 #pragma unroll
-        for (int r = 0; r < 16; r++) x[r] = lds[ntt_pad(base_idx + stride * r)];
+            for (int r = 0; r < 16; r++) x[r] = rd.at(lds, r);
+        }
         // no barrier here: a thread writes back exactly the 16 locations it read, nobody else touches them in this step
         ntt_r16_stage<0>(x, a.tw, tp, m, a.log_nmax);
         ntt_r16_stage<1>(x, a.tw, tp, m, a.log_nmax);
         ntt_r16_stage<2>(x, a.tw, tp, m, a.log_nmax);
         ntt_r16_stage<3>(x, a.tw, tp, m, a.log_nmax);
     }
+    {
+        const NttLdsWalk wr(base_idx, stride);
 #pragma unroll
-    for (int r = 0; r < 16; r++) lds[ntt_pad(base_idx + stride * r)] = x[r];
+        for (int r = 0; r < 16; r++) wr.at(lds, r) = x[r];
+    }
     __syncthreads();
+    const NttLdsWalk fin(t, T);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const u32 i = t + T * k;
-        const u32 src = (!SPLIT && a.bitrev_out) ? (__brev(i) >> (32 - logn)) : i;
-        u64 v = lds[ntt_pad(src)];
+        u64 v = (!SPLIT && a.bitrev_out) ? lds[ntt_pad(__brev(i) >> (32 - logn))] : fin.at(lds, k);
         if (post)
             v = gl::mul(v, post[(size_t)half * n + i]);
         else if (a.post_scalar != 1)
