@@ -23,13 +23,19 @@ using gl::u64;
 static const u64 UNSET = ~0ull;
 
 // ------------------------------------------------------------------------------------------- Poseidon
+// The hashing kernels are VALU-issue bound; left alone the register allocator takes 102 VGPRs (4 waves per SIMD), asked
+// for 5 waves it fits in 84 without spilling.
+#ifndef P2_HASH_WAVES_PER_EU
+#define P2_HASH_WAVES_PER_EU 5
+#endif
+#define P2_HASH_WAVES __attribute__((amdgpu_waves_per_eu(P2_HASH_WAVES_PER_EU, P2_HASH_WAVES_PER_EU)))
 // 12 lanes of state live in registers of ONE thread; one thread = one sponge.  (Leaf hashing has ~10^5..10^6
 // independent sponges per tree, so thread-per-sponge already fills the chip with coalesced column reads.)
 __device__ __forceinline__ void sponge_absorb_permute(u64* st) { glf::poseidon(st); }
 
 // Leaf digests of a column-major batch: digest[leaf] = hash_or_noop(row leaf of `cols` columns).
 // Columns >= active_cols are known-zero (never materialised).
-__global__ __launch_bounds__(256) void k_hash_leaves(const u64* __restrict__ data, int cols, int active_cols, size_t col_stride,
+__global__ __launch_bounds__(256) P2_HASH_WAVES void k_hash_leaves(const u64* __restrict__ data, int cols, int active_cols, size_t col_stride,
                                                       size_t batch_stride, size_t num_leaves, u64* __restrict__ digests,
                                                       size_t dig_batch_stride) {
     size_t leaf = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -57,7 +63,7 @@ __global__ __launch_bounds__(256) void k_hash_leaves(const u64* __restrict__ dat
 
 // FRI commit-phase leaves: leaf t = 16 consecutive extension values (bit-reversed order), flattened (c0,c1).
 // values: two component columns [2][len].
-__global__ __launch_bounds__(256) void k_hash_fri_leaves(const u64* __restrict__ vals, size_t len, size_t batch_stride, int arity,
+__global__ __launch_bounds__(256) P2_HASH_WAVES void k_hash_fri_leaves(const u64* __restrict__ vals, size_t len, size_t batch_stride, int arity,
                                                           u64* __restrict__ digests, size_t dig_batch_stride) {
     size_t leaf = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t num_leaves = len / arity;
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(256) void k_hash_fri_leaves(const u64* __restrict__
 }
 
 // One Merkle level: parent[i] = two_to_one(child[2i], child[2i+1]).
-__global__ __launch_bounds__(256) void k_merkle_level(const u64* __restrict__ child, u64* __restrict__ parent, size_t num_parents,
+__global__ __launch_bounds__(256) P2_HASH_WAVES void k_merkle_level(const u64* __restrict__ child, u64* __restrict__ parent, size_t num_parents,
                                                        size_t batch_stride) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= num_parents) return;
