@@ -38,14 +38,15 @@ __device__ __forceinline__ void sponge_absorb_permute(u64* st) { glf::poseidon(s
 __global__ __launch_bounds__(256) P2_HASH_WAVES void k_hash_leaves(const u64* __restrict__ data, int cols, int active_cols, size_t col_stride,
                                                       size_t batch_stride, size_t num_leaves, u64* __restrict__ digests,
                                                       size_t dig_batch_stride) {
-    size_t leaf = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (leaf >= num_leaves) return;
-    const u64* d = data + (size_t)blockIdx.y * batch_stride + leaf;
-    u64* out = digests + (size_t)blockIdx.y * dig_batch_stride + leaf * 4;
+    // (the output address is formed only at the end: nothing but the sponge state, the input pointer and the loop counter
+    // stays live across the permutations -- at 5 waves per SIMD every register counts)
+    if ((size_t)blockIdx.x * blockDim.x + threadIdx.x >= num_leaves) return;
+    const u64* d = data + (size_t)blockIdx.y * batch_stride + ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
     u64 st[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) st[i] = 0;
     if (cols <= 4) {
+        u64* out = digests + (size_t)blockIdx.y * dig_batch_stride + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
         for (int c = 0; c < 4; c++) out[c] = (c < cols && c < active_cols) ? d[(size_t)c * col_stride] : 0;
         return;
     }
@@ -53,10 +54,12 @@ __global__ __launch_bounds__(256) P2_HASH_WAVES void k_hash_leaves(const u64* __
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             int c = c0 + k;
-            if (c < cols) st[k] = c < active_cols ? d[(size_t)c * col_stride] : 0;
+            if (c < cols) st[k] = c < active_cols ? d[(size_t)k * col_stride] : 0;
         }
+        d += 8 * col_stride;
         glf::poseidon(st);
     }
+    u64* out = digests + (size_t)blockIdx.y * dig_batch_stride + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
 #pragma unroll
     for (int i = 0; i < 4; i++) out[i] = st[i];
 }
@@ -89,16 +92,21 @@ __global__ __launch_bounds__(256) P2_HASH_WAVES void k_hash_fri_leaves(const u64
 // One Merkle level: parent[i] = two_to_one(child[2i], child[2i+1]).
 __global__ __launch_bounds__(256) P2_HASH_WAVES void k_merkle_level(const u64* __restrict__ child, u64* __restrict__ parent, size_t num_parents,
                                                        size_t batch_stride) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= num_parents) return;
-    const u64* c = child + (size_t)blockIdx.y * batch_stride + 8 * i;
+    if ((size_t)blockIdx.x * blockDim.x + threadIdx.x >= num_parents) return;
     u64 st[12];
+    {
+        const u64* c = child + (size_t)blockIdx.y * batch_stride + 8 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
 #pragma unroll
-    for (int k = 0; k < 8; k++) st[k] = c[k];
+        for (int k = 0; k < 8; k++) st[k] = c[k];
+    }
+    {
+        u64 zero = 0;
+        asm("" : "+v"(zero));  // opaque: a known-zero capacity makes the first round a special case and costs 9 more registers
 #pragma unroll
-    for (int k = 8; k < 12; k++) st[k] = 0;
+        for (int k = 8; k < 12; k++) st[k] = zero;
+    }
     glf::poseidon(st);
-    u64* o = parent + (size_t)blockIdx.y * batch_stride + 4 * i;
+    u64* o = parent + (size_t)blockIdx.y * batch_stride + 4 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);  // formed late: see k_hash_leaves
 #pragma unroll
     for (int k = 0; k < 4; k++) o[k] = st[k];
 }
