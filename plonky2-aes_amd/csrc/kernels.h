@@ -743,23 +743,49 @@ struct ChalState {
     u64 out[8];
     u32 in_len, out_len;
 };
+// The sponge of one proof is spread over a 16-lane group (glf::poseidon_coop): lane i holds state word i, input-buffer
+// word i and output-buffer word i.  The ~110 permutations of a proof's Fiat-Shamir chain are strictly sequential; with one
+// thread per proof (round 1) a single lane's 19 k-instruction stream per permutation set the latency of every stage.
 struct DevChallenger {
-    ChalState s;
+    u64 w, inb, outb;     // this lane's word of state / in / out
+    u32 in_len, out_len;  // the same in every lane of the group
+    u32 i;                // lane within the group
+    int gbase;            // first lane of the group within the wave
+    __device__ void load(const ChalState& s) {
+        w = i < 12 ? s.state[i] : 0;
+        inb = i < 8 ? s.in[i] : 0;
+        outb = i < 8 ? s.out[i] : 0;
+        in_len = s.in_len;
+        out_len = s.out_len;
+    }
+    __device__ void store(ChalState& s) const {
+        if (i < 12) s.state[i] = w;
+        if (i < 8) {
+            s.in[i] = inb;
+            s.out[i] = outb;
+        }
+        if (i == 0) {
+            s.in_len = in_len;
+            s.out_len = out_len;
+        }
+    }
     __device__ void duplexing() {
-        for (u32 i = 0; i < s.in_len; i++) s.state[i] = s.in[i];
-        s.in_len = 0;
-        glf::poseidon(s.state);
-        for (int i = 0; i < 8; i++) s.out[i] = s.state[i];
-        s.out_len = 8;
+        if (i < in_len) w = inb;
+        in_len = 0;
+        w = glf::poseidon_coop(w, i);
+        outb = w;
+        out_len = 8;
     }
-    __device__ void observe(u64 x) {
-        s.out_len = 0;
-        s.in[s.in_len++] = x;
-        if (s.in_len == 8) duplexing();
+    __device__ void observe(u64 x) {  // x: the same value in every lane of the group
+        out_len = 0;
+        if (i == in_len) inb = x;
+        in_len++;
+        if (in_len == 8) duplexing();
     }
-    __device__ u64 challenge() {
-        if (s.in_len != 0 || s.out_len == 0) duplexing();
-        return s.out[--s.out_len];
+    __device__ u64 challenge() {  // returns the value to every lane of the group
+        if (in_len != 0 || out_len == 0) duplexing();
+        --out_len;
+        return glf::shfl64(outb, gbase + (int)out_len);
     }
 };
 
@@ -794,53 +820,69 @@ struct ChalArgs {
 // stage 1: observe zs cap; alphas            stage 2: observe quotient cap; zeta
 // stage 3: observe openings; fri_alpha       stage 4: observe FRI cap (round aux); beta
 // stage 5: observe final poly                stage 6: observe pow witness; response; query indices
-__global__ void k_challenger(ChalArgs a) {
-    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= a.batch) return;
+__global__ __launch_bounds__(64) void k_challenger(ChalArgs a) {
+    // 16 lanes per proof, 4 proofs per wave; a group past the end of the batch replays the last proof without storing
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool real = (t >> 4) < a.batch;
+    const u32 p = real ? (t >> 4) : a.batch - 1;
     DevChallenger c;
+    c.i = t & 15;
+    c.gbase = (int)(threadIdx.x & 63) & ~15;
+    const bool writer = real && c.i == 0;
     u64* ch = a.chal + (size_t)p * CH_WORDS;
     if (a.stage == 0) {
-        for (int i = 0; i < 12; i++) c.s.state[i] = 0;
-        c.s.in_len = c.s.out_len = 0;
+        c.w = c.inb = c.outb = 0;
+        c.in_len = c.out_len = 0;
         for (int i = 0; i < 4; i++) c.observe(a.digest[i]);
         for (int i = 0; i < 4; i++) c.observe(0);
     } else {
-        c.s = a.st[p];
+        c.load(a.st[p]);
     }
     const u64* ob = a.observe + (size_t)p * a.observe_stride;
     if (a.stage == 6) {
         c.observe(ch[CH_POW]);
         (void)c.challenge();
-        for (u32 q = 0; q < a.aux; q++) ch[CH_QUERY + q] = c.challenge() % a.mod;
-        a.st[p] = c.s;
+        for (u32 q = 0; q < a.aux; q++) {
+            const u64 v = c.challenge() % a.mod;
+            if (writer) ch[CH_QUERY + q] = v;
+        }
+        if (real) c.store(a.st[p]);
         return;
     }
     for (u32 i = 0; i < a.observe_len; i++) c.observe(ob[i]);
     if (a.stage == 0) {
-        for (int i = 0; i < 2; i++) ch[CH_BETAS + i] = c.challenge();
-        for (int i = 0; i < 2; i++) ch[CH_GAMMAS + i] = c.challenge();
-        if (a.aux) {
-            for (int i = 0; i < 2; i++) ch[CH_DELTAS + i] = ch[CH_BETAS + i];
-            for (int i = 0; i < 2; i++) ch[CH_DELTAS + 2 + i] = ch[CH_GAMMAS + i];
-            for (int i = 0; i < 4; i++) ch[CH_DELTAS + 4 + i] = c.challenge();
+        u64 bg[4], dl[4];
+        for (int i = 0; i < 4; i++) bg[i] = c.challenge();  // betas, gammas
+        if (a.aux)
+            for (int i = 0; i < 4; i++) dl[i] = c.challenge();
+        if (writer) {
+            for (int i = 0; i < 2; i++) ch[CH_BETAS + i] = bg[i];
+            for (int i = 0; i < 2; i++) ch[CH_GAMMAS + i] = bg[2 + i];
+            if (a.aux) {
+                for (int i = 0; i < 4; i++) ch[CH_DELTAS + i] = bg[i];
+                for (int i = 0; i < 4; i++) ch[CH_DELTAS + 4 + i] = dl[i];
+            }
         }
     } else if (a.stage == 1) {
-        for (int i = 0; i < 2; i++) ch[CH_ALPHAS + i] = c.challenge();
+        const u64 a0 = c.challenge(), a1 = c.challenge();
+        if (writer) ch[CH_ALPHAS] = a0, ch[CH_ALPHAS + 1] = a1;
     } else if (a.stage == 2) {
-        u64 z0 = c.challenge(), z1 = c.challenge();
-        ch[CH_ZETA] = z0;
-        ch[CH_ZETA + 1] = z1;
-        // "Opening point is in the subgroup."
-        E2 zp = gl::exp_pow2(gl::e2(z0, z1), (int)a.aux);
-        if (zp.a == 1 && zp.b == 0) atomicMax(&a.status[p], 3);
+        const u64 z0 = c.challenge(), z1 = c.challenge();
+        if (writer) {
+            ch[CH_ZETA] = z0;
+            ch[CH_ZETA + 1] = z1;
+            // "Opening point is in the subgroup."
+            E2 zp = gl::exp_pow2(gl::e2(z0, z1), (int)a.aux);
+            if (zp.a == 1 && zp.b == 0) atomicMax(&a.status[p], 3);
+        }
     } else if (a.stage == 3) {
-        ch[CH_FRI_ALPHA] = c.challenge();
-        ch[CH_FRI_ALPHA + 1] = c.challenge();
+        const u64 f0 = c.challenge(), f1 = c.challenge();
+        if (writer) ch[CH_FRI_ALPHA] = f0, ch[CH_FRI_ALPHA + 1] = f1;
     } else if (a.stage == 4) {
-        ch[CH_FRI_BETAS + 2 * a.aux] = c.challenge();
-        ch[CH_FRI_BETAS + 2 * a.aux + 1] = c.challenge();
+        const u64 b0 = c.challenge(), b1 = c.challenge();
+        if (writer) ch[CH_FRI_BETAS + 2 * a.aux] = b0, ch[CH_FRI_BETAS + 2 * a.aux + 1] = b1;
     }
-    a.st[p] = c.s;
+    if (real) c.store(a.st[p]);
 }
 
 // Proof-of-work grinding: smallest witness w such that the duplex response has >= pow_bits leading zeros.

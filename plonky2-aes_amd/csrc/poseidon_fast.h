@@ -325,4 +325,62 @@ GL_HD void poseidon(u64* s) {
     for (int i = 0; i < 12; i++) s[i] = canon(s[i]);
 }
 
+#if defined(__HIPCC__)
+// ---- cooperative form: ONE sponge state spread over 12 lanes of a 16-lane group (lane i holds word i; lanes 12..15 are
+// idle and must hold 0).  Same permutation, same constants; the linear layers gather the other words with cross-lane
+// reads (ds_bpermute) and the partial rounds' dot product is a 4-step butterfly sum.  4.3 k VALU instructions per lane
+// instead of 18.9 k: this is for the Fiat-Shamir chain (k_challenger), where ~110 permutations per proof are strictly
+// sequential and a thread-per-sponge kernel leaves a single proof waiting on one lane's instruction stream.
+__device__ __forceinline__ u64 shfl64(u64 v, int src_lane) { return (u64)__shfl((unsigned long long)v, src_lane, 64); }
+__device__ inline u64 poseidon_coop(u64 w, const u32 i /* lane within the 16-lane group */) {
+    const int lane = (int)(threadIdx.x & 63), gbase = lane & ~15;
+    const bool live = i < 12;
+    const u32 ii = live ? i : 0;  // index clamp for the idle lanes' (unused) constant loads
+    const unsigned long long* RC = (const unsigned long long*)gl::D_POSEIDON_RC;
+    // circulant MDS row of this lane on the group's words z, plus the next constant
+    auto mds = [&](u64 z, u64 rc) -> u64 {
+        const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+        u64 al = (u32)rc, ah = rc >> 32;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            u32 src = i + k;
+            src = src >= 12 ? src - 12 : src;  // (i + k) mod 12 for live lanes; idle lanes read some lane of the group, unused
+            const u64 x = shfl64(z, gbase + (int)(src & 15));
+            const u32 c = C[k] + ((k == 0 && i == 0) ? 8u : 0u);
+            al += (x & gl::EPS) * c;
+            ah += (x >> 32) * c;
+        }
+        return fold_al_ah(al, ah);
+    };
+    w = live ? add_wrap(w, RC[ii]) : 0;
+    for (int r = 0; r < 3; r++) w = mds(sbox7(w), live ? RC[12 * (r + 1) + ii] : 0);
+    {   // 4th full round with the dense layer merged in (PF_E): lane 0 takes the MDS row, lanes 1..11 a row of E
+        const u64 z = sbox7(w);
+        const u64 row0 = mds(z, i == 0 ? PF_A[0] : 0);
+        const u32 er = (live && i >= 1) ? i - 1 : 0;
+        Acc a;
+        a.init();
+#pragma unroll
+        for (int c = 0; c < 12; c++) a.fma(PF_E[er * 12 + c], shfl64(z, gbase + c));
+        const u64 rowe = a.reduce();
+        w = i == 0 ? row0 : (live ? rowe : 0);
+    }
+    for (int pr = 0; pr < 22; pr++) {
+        const u64 z0 = shfl64(sbox7(w), gbase);  // lane 0's S-box output, to everybody
+        const u32 cj = (live && i >= 1) ? pr * 11 + (i - 1) : 0;
+        const u64 coef = i == 0 ? 25 : (live ? PF_WHAT[cj] : 0);
+        u64 term = canon(mulr(coef, i == 0 ? z0 : w));  // idle lanes: 0
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) term = gl::add(term, shfl64(term, lane ^ d));
+        const u64 s0n = gl::add(term, pr < 21 ? PF_A[pr + 1] : PF_RC26[0]);
+        const u64 wj = mulr_add((live && i >= 1) ? PF_V[cj] : 0, z0, w);
+        w = i == 0 ? s0n : wj;
+    }
+    if (live && i >= 1) w = add_wrap(w, PF_RC26[ii]);
+    for (int r = 26; r < 29; r++) w = mds(sbox7(w), live ? RC[12 * (r + 1) + ii] : 0);
+    w = mds(sbox7(w), 0);
+    return live ? canon(w) : 0;
+}
+#endif
+
 }  // namespace glf

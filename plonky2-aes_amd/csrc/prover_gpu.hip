@@ -296,7 +296,7 @@ static int challenger(p2_circuit* C, u32 stage, const u64* observe, size_t strid
     a.mod = mod;
     a.digest = C->d_digest;
     a.status = C->cur->d_status;
-    LAUNCH(C, "challenger", k_challenger, g1(batch, 64), dim3(64), 0, a);
+    LAUNCH(C, "challenger", k_challenger, g1((size_t)batch * 16, 64), dim3(64), 0, a);  // a 16-lane group per proof
     return 0;
 }
 
@@ -1463,6 +1463,27 @@ __global__ void k_selftest(unsigned long long* bad, u64 seed, size_t threads) {
     for (int k = 0; k < 12; k++) b += s0[k] != s1[k];
     if (b) atomicAdd(bad, b);
 }
+// the cooperative permutation (16 lanes per state) against the plain one: every group draws its own state
+__global__ __launch_bounds__(64) void k_selftest_coop(unsigned long long* bad, u64 seed) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x, grp = t >> 4, i = t & 15;
+    u64 st[12];
+    u64 x = (seed | 1) + 0x9E3779B97F4A7C15ull * (grp + 1);
+    for (int k = 0; k < 12; k++) {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        st[k] = (grp & 7) == 0 ? (k & 1 ? gl::P - 1 : 0) : x % gl::P;
+    }
+    u64 mine = 0;
+    for (int k = 0; k < 12; k++)
+        if ((u32)k == i) mine = st[k];
+    const u64 got = glf::poseidon_coop(mine, i);
+    gl::poseidon(st);  // every lane redundantly, the textbook form
+    u64 want = 0;
+    for (int k = 0; k < 12; k++)
+        if ((u32)k == i) want = st[k];
+    if (got != want) atomicAdd(bad, 1ull);
+}
 }  // namespace p2k
 
 int p2_selftest_device(uint64_t seed, size_t threads, int device) {
@@ -1470,6 +1491,7 @@ int p2_selftest_device(uint64_t seed, size_t threads, int device) {
     unsigned long long* d = nullptr;
     if (hipMalloc((void**)&d, 8) != hipSuccess || hipMemset(d, 0, 8) != hipSuccess) return set_error("hipMalloc failed"), -P2_ERR_HIP;
     hipLaunchKernelGGL(p2k::k_selftest, dim3((u32)((threads + 255) / 256)), dim3(256), 0, 0, d, (u64)seed, threads);
+    hipLaunchKernelGGL(p2k::k_selftest_coop, dim3((u32)std::min<size_t>(std::max<size_t>(threads / 64, 1), 4096)), dim3(64), 0, 0, d, (u64)seed);
     unsigned long long h = 0;
     hipError_t e = hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
     (void)hipFree(d);
