@@ -886,42 +886,59 @@ __global__ __launch_bounds__(64) void k_challenger(ChalArgs a) {
 }
 
 // Proof-of-work grinding: smallest witness w such that the duplex response has >= pow_bits leading zeros.
-// grid = (proofs, POW_BLOCKS): one 256-candidate block per workgroup, proofs varying fastest so that the workgroups
-// resident at any moment cover the low candidate ranges of every proof; a workgroup whose whole block lies above the
-// best witness found so far exits at once (the common case: ~2^pow_bits candidates are needed per proof).
-// 2^21 candidates per proof: the probability that none works is exp(-32) (reported as status 4, never a bad proof).
-// (A persistent strided loop was measured 3x slower: only half of its workgroups are resident at once and the
-// unluckiest proof of a chunk serialises ~100 us iterations.)
-static const u32 POW_BLOCKS = 1u << 13;  // x 256 candidates
-__global__ __launch_bounds__(256) void k_pow(const ChalState* st, u64* chal, int pow_bits, unsigned long long* best /*[batch]*/) {
+// One 256-candidate block per workgroup; a workgroup whose whole block lies above the best witness found so far exits at
+// once.  2^21 candidates per proof are covered in three phases of 2^16, 3 * 2^16 and 7 * 2^18 candidates: ~2^16 candidates
+// are needed per proof on average, so the first phase (grid = proofs x 256 blocks, proofs varying fastest) settles 63 % of a
+// chunk, and the later phases run only over the COMPACTED list of unsolved proofs (k_pow_compact) with a small grid of list
+// slots.  Round 1 launched proofs x 8192 workgroups in one go: a million of them per chunk did nothing but one memory-side
+// atomic on one of 128 addresses and exit, which cost as much as the hashing itself.
+// The probability that 2^21 candidates hold no witness is exp(-32) (reported as status 4, never a bad proof).
+static const u32 POW_PHASE_BLOCKS[3] = {1u << 8, 3u << 8, 7u << 10};  // x 256 candidates: 2^16 + 3 * 2^16 + 7 * 2^18 = 2^21
+static const u32 POW_PHASE_SLOTS[3] = {0, 64, 8};                      // list slots of the grid (phase 0 addresses proofs directly)
+__global__ __launch_bounds__(256) void k_pow(const ChalState* st, u64* chal, int pow_bits, unsigned long long* best /*[batch]*/, u32 block0,
+                                             const u32* list /* null: blockIdx.x is the proof */, const u32* count) {
     // The candidate is the next observed element: whether or not it completes the rate, the response is word 7 of
     // permute(state overwritten by the buffered inputs and the candidate).  The overwritten state is the same for every
     // candidate of a proof, so it is staged once per workgroup in LDS and the permutation runs entirely in registers.
     __shared__ u64 sh[12];
     __shared__ u32 sh_pos;
-    const u32 p = blockIdx.x;
-    const u64 block_start = (u64)blockIdx.y * blockDim.x;
-    // `best` is updated by workgroups on all 8 XCDs; their L2s are not coherent with each other, so a plain (even sc1)
-    // load can keep returning this XCD's stale copy.  A no-op atomic min executes at the memory side and returns the
-    // current value; one lane per workgroup issues it.
     __shared__ unsigned long long sh_cur;
-    if (threadIdx.x == 0) sh_cur = atomicMin(&best[p], ~0ull);
-    __syncthreads();
-    if (sh_cur < block_start) return;  // workgroup-uniform
-    if (threadIdx.x < 12) {
-        const ChalState* s = st + p;
-        u32 i = threadIdx.x;
-        sh[i] = (i < s->in_len) ? s->in[i] : s->state[i];
-        if (i == 0) sh_pos = s->in_len;
-    }
-    __syncthreads();
-    const u64 cand = block_start + threadIdx.x;
-    const u32 pos = sh_pos;
-    u64 r[12];
+    const u64 block_start = ((u64)block0 + blockIdx.y) * blockDim.x;
+    const u32 n_items = list ? *count : gridDim.x;
+    for (u32 item = blockIdx.x; item < n_items; item += gridDim.x) {  // workgroup-uniform; one trip unless the list outgrows the grid
+        const u32 p = list ? list[item] : item;
+        // `best` is updated by workgroups on all 8 XCDs; their L2s are not coherent with each other, so a plain (even sc1)
+        // load can keep returning this XCD's stale copy.  A no-op atomic min executes at the memory side and returns the
+        // current value; one lane per workgroup issues it.
+        __syncthreads();
+        if (threadIdx.x == 0) sh_cur = atomicMin(&best[p], ~0ull);
+        __syncthreads();
+        if (sh_cur < block_start) continue;  // workgroup-uniform
+        if (threadIdx.x < 12) {
+            const ChalState* s = st + p;
+            u32 i = threadIdx.x;
+            sh[i] = (i < s->in_len) ? s->in[i] : s->state[i];
+            if (i == 0) sh_pos = s->in_len;
+        }
+        __syncthreads();
+        const u64 cand = block_start + threadIdx.x;
+        const u32 pos = sh_pos;
+        u64 r[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) r[i] = ((u32)i == pos) ? cand : sh[i];
-    glf::poseidon(r);
-    if ((r[7] >> (64 - pow_bits)) == 0) atomicMin(&best[p], (unsigned long long)cand);
+        for (int i = 0; i < 12; i++) r[i] = ((u32)i == pos) ? cand : sh[i];
+        glf::poseidon(r);
+        if ((r[7] >> (64 - pow_bits)) == 0) atomicMin(&best[p], (unsigned long long)cand);
+    }
+}
+// list of the proofs that still have no witness (any order), for the next phase
+__global__ void k_pow_compact(const unsigned long long* best, u32 batch, u32* list, u32* count) {
+    __shared__ u32 n;
+    if (threadIdx.x == 0) n = 0;
+    __syncthreads();
+    for (u32 p = threadIdx.x; p < batch; p += blockDim.x)
+        if (best[p] == ~0ull) list[atomicAdd(&n, 1u)] = p;
+    __syncthreads();
+    if (threadIdx.x == 0) *count = n;
 }
 __global__ void k_pow_finish(u64* chal, const unsigned long long* best, u32 batch, int* status) {
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;

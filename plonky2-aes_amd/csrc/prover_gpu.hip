@@ -55,6 +55,7 @@ struct Workspace {
     u64* d_fri_vals[9] = {nullptr};  // [2][8 n_r]
     Tree fri_tree[9];
     unsigned long long* d_pow_best = nullptr;
+    u32* d_pow_list = nullptr;  // [chunk] unsolved proofs + [1] their count (proof-of-work phases)
     uint8_t* d_proofs = nullptr;
     PolyRef* d_polyrefs = nullptr;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
@@ -561,6 +562,7 @@ static int build_workspace(p2_circuit* C, Workspace* W, size_t chunk, u32 ws_inp
         }
     }
     WS_ALLOC(W->d_pow_best, chunk);
+    WS_ALLOC(W->d_pow_list, chunk + 1);
     WS_ALLOC(W->d_proofs, chunk * C->pbytes);
 #undef WS_ALLOC
     C->cur = W;
@@ -844,7 +846,17 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         if (challenger(C, 5, C->cur->d_obs, (size_t)2 * C->n_obs, (u32)(2 * fl), 0, 0, B)) return P2_ERR_HIP;
         // proof of work
         HIPCHECK(hipMemsetAsync(C->cur->d_pow_best, 0xFF, (size_t)B * 8, st));
-        LAUNCH(C, "pow", k_pow, dim3(B, POW_BLOCKS), dim3(256), 0, C->cur->d_chal_state, C->cur->d_chal, (int)c.cfg.pow_bits, C->cur->d_pow_best);
+        {
+            u32 block0 = 0;
+            for (int ph = 0; ph < 3; ph++) {
+                u32* list = ph ? C->cur->d_pow_list : nullptr;
+                if (ph) LAUNCH(C, "pow", k_pow_compact, dim3(1), dim3(256), 0, C->cur->d_pow_best, B, C->cur->d_pow_list, C->cur->d_pow_list + C->chunk);
+                const u32 slots = ph ? std::min<u32>(B, POW_PHASE_SLOTS[ph]) : B;
+                LAUNCH(C, "pow", k_pow, dim3(slots, POW_PHASE_BLOCKS[ph]), dim3(256), 0, C->cur->d_chal_state, C->cur->d_chal, (int)c.cfg.pow_bits, C->cur->d_pow_best,
+                       block0, (const u32*)list, (const u32*)(list ? list + C->chunk : nullptr));
+                block0 += POW_PHASE_BLOCKS[ph];
+            }
+        }
         LAUNCH(C, "pow_finish", k_pow_finish, g1(B, 64), dim3(64), 0, C->cur->d_chal, C->cur->d_pow_best, B, C->cur->d_status);
         if (challenger(C, 6, C->cur->d_obs, 0, 0, c.cfg.num_query_rounds, (u64)N, B)) return P2_ERR_HIP;
         // 10. proof assembly
