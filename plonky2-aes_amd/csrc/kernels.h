@@ -227,24 +227,33 @@ struct NttLdsWalk {
     __device__ __forceinline__ NttLdsWalk(u32 base, u32 stride) : a0(8 * ntt_pad(base)), step(stride >= 16 ? 8 * (stride + (stride >> 4)) : 8 * stride) {}
     __device__ __forceinline__ u64& at(u64* lds, int r) const { return *(u64*)((char*)lds + (a0 + (u32)r * step)); }
 };
-// stages `first`..3 of a step with stride 2^m on the 16 points x[r] (r <-> index base + t' + r * 2^m)
-template <int A>
-__device__ __forceinline__ void ntt_r16_stage(u64* x, const u64* __restrict__ tw, u32 tp, int m, int tw_log /*log2 of the table order*/) {
-    constexpr int half = 8 >> A;
-    // h = 2^(m + 3 - A); twiddle of pair (r, r + half): w_{2h}^(t' + 2^m (r mod half)) = table[(t' + 2^m (r mod half)) << (tw_log - (m + 4 - A))]
-    const int sh = tw_log - (m + 4 - A);
-    u64 w[half];
-    // 32-bit byte offsets from the uniform table base (the table is at most 2^14 * 8 B): one v_add per twiddle instead
-    // of a 64-bit shift-and-add address each
-    const u32 off0 = tp << (sh + 3), dj = 1u << (m + sh + 3);
+// The 15 twiddles of a four-stage step with stride 2^m (8 + 4 + 2 + 1 for the stages with half-size 8, 4, 2, 1 times 2^m):
+// stage A (h = 2^(m + 3 - A)), pair (r, r + (8 >> A)): w_{2h}^(t' + 2^m (r mod (8 >> A))) = table[(t' + 2^m j) << (tw_log - (m + 4 - A))].
+// They are loaded a whole step ahead -- before the LDS exchange that precedes their use -- so that their L2 latency hides
+// under the barrier (rocprofv3: the kernel's waves were parked 55 % of the time; a wave's loads retire in order, so the
+// only place to hide them is ahead of work the same wave does anyway).
+__device__ __forceinline__ void ntt_r16_load_tw(u64* w, const u64* __restrict__ tw, u32 tp, int m, int tw_log, int nstages) {
+    // 32-bit byte offsets from the uniform table base (the table is at most 2^14 * 8 B)
 #pragma unroll
-    for (int j = 0; j < half; j++) w[j] = *(const u64*)((const char*)tw + (off0 + (u32)j * dj));
+    for (int A = 0; A < 4; A++) {
+        if (A >= nstages) break;
+        const int half = 8 >> A, base = 16 - 2 * half, sh = tw_log - (m + 4 - A);
+        const u32 off0 = tp << (sh + 3), dj = 1u << (m + sh + 3);
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (j < half) w[base + j] = *(const u64*)((const char*)tw + (off0 + (u32)j * dj));
+    }
+}
+// stage A of a step on the 16 points x[r] (r <-> index base + t' + r * 2^m), twiddles from ntt_r16_load_tw
+template <int A>
+__device__ __forceinline__ void ntt_r16_stage(u64* x, const u64* w) {
+    constexpr int half = 8 >> A, base = 16 - 2 * half;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         if (r & half) continue;
         const u64 u = x[r], v = x[r + half];
         x[r] = gl::add(u, v);
-        x[r + half] = gl::mul(gl::sub(u, v), w[r % half]);
+        x[r + half] = gl::mul(gl::sub(u, v), w[base + r % half]);
     }
 }
 // SPLIT: one workgroup transforms HALF a column -- the first stage (h = n/2) is done while loading (every workgroup reads
@@ -304,15 +313,17 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
     // first step: the leading rem = logn mod 4 (or 4) stages on the whole array, stride M = n / 16
     // (with M = n / 16 stage A has h = n / 2^(A+1): these ARE the first `rem` stages of the whole transform)
     const int rem = (logn & 3) ? (logn & 3) : 4;
-    {
-        const int m = logn - 4;
-        ntt_r16_stage<0>(x, a.tw, t, m, a.log_nmax);
-        if (rem >= 2) ntt_r16_stage<1>(x, a.tw, t, m, a.log_nmax);
-        if (rem >= 3) ntt_r16_stage<2>(x, a.tw, t, m, a.log_nmax);
-        if (rem >= 4) ntt_r16_stage<3>(x, a.tw, t, m, a.log_nmax);
-    }
+    u64 w[15];
+    ntt_r16_load_tw(w, a.tw, t, logn - 4, a.log_nmax, rem);
+    ntt_r16_stage<0>(x, w);
+    if (rem >= 2) ntt_r16_stage<1>(x, w);
+    if (rem >= 3) ntt_r16_stage<2>(x, w);
+    if (rem >= 4) ntt_r16_stage<3>(x, w);
     u32 base_idx = t, stride = T;  // the thread's 16 points are base_idx + stride * r
     for (int logN = logn - rem; logN >= 4; logN -= 4) {
+        const int m = logN - 4;
+        const u32 tp = t & ((1u << m) - 1);
+        ntt_r16_load_tw(w, a.tw, tp, m, a.log_nmax, 4);  // issued before the exchange: in flight across the barrier
         // exchange: write the points back where they live, read the next step's 16
         {
             const NttLdsWalk wr(base_idx, stride);
@@ -320,8 +331,6 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
             for (int r = 0; r < 16; r++) wr.at(lds, r) = x[r];
         }
         __syncthreads();
-        const int m = logN - 4;
-        const u32 tp = t & ((1u << m) - 1);
         base_idx = ((t >> m) << logN) | tp;
         stride = 1u << m;
         {
@@ -330,10 +339,10 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
             for (int r = 0; r < 16; r++) x[r] = rd.at(lds, r);
         }
         // no barrier here: a thread writes back exactly the 16 locations it read, nobody else touches them in this step
-        ntt_r16_stage<0>(x, a.tw, tp, m, a.log_nmax);
-        ntt_r16_stage<1>(x, a.tw, tp, m, a.log_nmax);
-        ntt_r16_stage<2>(x, a.tw, tp, m, a.log_nmax);
-        ntt_r16_stage<3>(x, a.tw, tp, m, a.log_nmax);
+        ntt_r16_stage<0>(x, w);
+        ntt_r16_stage<1>(x, w);
+        ntt_r16_stage<2>(x, w);
+        ntt_r16_stage<3>(x, w);
     }
     {
         const NttLdsWalk wr(base_idx, stride);
