@@ -1,12 +1,16 @@
-// Poseidon-12 for the hashing kernels: same permutation as gl::poseidon (gl.h), restructured for VALU issue slots:
-//   * lazy reduction -- state words are arbitrary u64 representatives (not < p) inside the permutation; every
-//     product is reduced once from 128 bits without the final conditional subtraction; outputs are canonicalised;
-//   * the 22 partial rounds use the sparse-matrix form derived by tools/gen_poseidon_fast.py: 23 multiply-accumulates
-//     per round instead of a 144-term MDS, with the 12-term dot product accumulated in 192 bits and reduced once.
-//   * reductions, the accumulator fold and the 128-bit add of the partial rounds are carry chains on 32-bit halves: a
-//     64-bit compare-and-select costs 5.5 issue slots on gfx950 and the textbook reduce128 has two of them.
-// Measured on MI355X (tools/microbench/int_rates.hip): v_mad_u64_u32 issues at ~1.8x the cost of a simple VALU op,
-// so the win comes from removing instructions, not from swapping multiply flavours.
+// Poseidon-12 for the hashing kernels: same permutation as gl::poseidon (gl.h), restructured for VALU issue slots
+// (18.9 k VALU instructions per permutation; the plain 30-round form compiles to 41 k):
+//   * lazy reduction -- state words are arbitrary u64 representatives (not < p) inside the permutation; every product is
+//     reduced once from 128 bits without canonicalisation; outputs are canonicalised;
+//   * multiply-reduce built from v_mad_u64_u32 (gl::mulr_add_dev): the mad is a 64-bit adder with a free multiplier and a
+//     carry-out, and costs what ONE 32-bit add-with-carry costs (tools/microbench/valu_rates.hip);
+//   * round constants are never added on their own: every linear layer starts its accumulators from the constants of the
+//     layer that follows;
+//   * the 22 partial rounds use the sparse-matrix form derived by tools/gen_poseidon_fast.py: 23 multiply-accumulates per
+//     round instead of a 144-term MDS, the 12-term dot product in a carry-counting accumulator reduced once, and the dense
+//     11x11 layer that opens them merged into the fourth full round's linear step (PF_E);
+//   * poseidon_coop: one state over 12 lanes of a 16-lane group, for the sequential Fiat-Shamir chain.
+// The host build of the same functions (plain 128-bit arithmetic) is what p2_selftest_host and the CPU tests exercise.
 #pragma once
 #include "gl.h"
 
@@ -40,7 +44,7 @@ GL_HD void mul128(u64 a, u64 b, u64& hi, u64& lo) {
 // T = lo + (hl << 32) - (hl + hh) is formed with 32-bit add/subtract-with-carry chains; the number of 2^64 wraps,
 // net = carry - borrow in {-1, 0, 1}, is folded back as T - net * p = T - (net << 32) ... + net, again on the halves, so no
 // 64-bit compare-and-select is needed: the compiler's version of plonky2's reduce128 spends two of those per reduction
-// (v_cmp_lt_u64 + 64-bit add + two v_cndmask + hazard padding, 5.5 issue slots each -- tools/microbench/int_rates.hip).
+// (v_cmp_lt_u64 + 64-bit add + two v_cndmask, and a v_cndmask on VCC alone costs 23 cycles -- tools/microbench/valu_rates.hip).
 // The result T - net * p lies in [0, 2^64) for every input (checked against 128-bit arithmetic on 2*10^8 inputs and all
 // combinations of extreme halves).
 GL_HD u64 red128(u64 hi, u64 lo) {
@@ -74,12 +78,6 @@ GL_HD u64 mulr(u64 a, u64 b) {
     mul128(a, b, hi, lo);
     return red128(hi, lo);
 #endif
-}
-// a arbitrary u64, c canonical (< p): cannot overflow twice
-GL_HD u64 add_canon(u64 a, u64 c) {
-    u64 r = a + c;
-    if (r < a) r += gl::EPS;
-    return r;
 }
 GL_HD u64 canon(u64 a) {
 #if defined(__HIP_DEVICE_COMPILE__)
