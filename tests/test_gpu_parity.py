@@ -571,3 +571,17 @@ def test_zk_full_width_key_and_os_key(gpu, orc):
     assert pa != pb
     a.verify(pa)
     b.verify(pb)
+
+
+def test_pow_phases_find_the_smallest_witness(gpu, orc):
+    """The proof-of-work search runs in three phases (2^16, then up to 2^18, then up to 2^21 candidates), the later ones
+    over a compacted list of the proofs still unsolved.  The oracle takes the SMALLEST witness; 24 small proofs, all
+    compared byte for byte, put several witnesses beyond the first phase (each proof: 37 %) -- asserted, so that the later
+    phases are known to have produced some of the proofs compared here."""
+    pairs = [((7 * i + 1) & 0xFF, (13 * i + 5) & 0xFF) for i in range(24)]
+    data, pws = circuits.gf_2_8_add(gpu, pairs)
+    proofs, status = _gpu_vs_oracle(gpu, orc, data, pws, exact=len(pws))
+    assert status == [0] * len(pws)
+    witnesses = [int.from_bytes(p[-8:], "little") for p in proofs]
+    assert sum(w >= 1 << 16 for w in witnesses) >= 3, witnesses
+    assert len(set(proofs)) == len(proofs)
