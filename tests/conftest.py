@@ -23,5 +23,8 @@ def pkg():
 @pytest.fixture(scope="session")
 def orc():
     import oracle_lib
-    oracle_lib.lib()
+    # the oracle does not scale past one socket's worth of threads (tools/orc_scale.py: 1.9 s per AES-GCM 1 KiB proof on 32
+    # threads, 3.1 s on the 128 of the GPU boxes' hosts): cap it -- the GPU suite spends most of its time in the oracle
+    L = oracle_lib.lib()
+    L.orc_set_num_threads(min(L.orc_num_threads(), 32))
     return oracle_lib
