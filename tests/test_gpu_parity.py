@@ -575,6 +575,23 @@ def test_zk_full_width_key_and_os_key(gpu, orc):
     b.verify(pb)
 
 
+def test_gpu_proofs_match_the_frozen_digests(gpu):
+    """The GPU prover against tests/golden/proof_digests.json WITHOUT the oracle in the loop: blob, verifier data and proof
+    bytes of seven fixed circuits and inputs by SHA-256 (the fixture was written by the oracle, tools/make_proof_digests.py;
+    the CPU suite checks the oracle against it)."""
+    import digest_cases as D
+    gold = D.fixture()
+    for name, (data, pws) in D.cases(gpu):
+        want = gold["cases"][name]
+        assert hashlib.sha256(data.blob).hexdigest() == want["blob_sha256"], name
+        assert D.sha_words(data.verifier_data()) == want["verifier_data_sha256"], name
+        if name.startswith("zk_"):
+            data.set_zk_key(D.ZK_KEY)
+        proof = data.prove(pws[0])
+        assert len(proof) == want["proof_bytes"] and hashlib.sha256(proof).hexdigest() == want["proof_sha256"], name
+        data.verify(proof)
+
+
 def test_pow_phases_find_the_smallest_witness(gpu, orc):
     """The proof-of-work search runs in three phases (2^16, then up to 2^18, then up to 2^21 candidates), the later ones
     over a compacted list of the proofs still unsolved.  The oracle takes the SMALLEST witness; 24 small proofs, all

@@ -612,3 +612,20 @@ def test_rust_ffi_matches_the_c_header(pkg):
                 "multiply_point", "add_point", "add_virtual_biguint320_target", "decompress_into_subgroup", "compress_from_subgroup",
                 "new_rand_from_subgroup", "fn generator()", "fn inverse("):
         assert sym in lib_rs, "shim crate lacks %s" % sym
+
+
+def test_proof_digests_are_frozen(pkg, orc):
+    """tests/golden/proof_digests.json: the compiled circuit blob, the verifier data and the oracle's proof bytes for seven of
+    the reference's circuit tests with their fixed inputs, by SHA-256.  The fixture is this build's own output (the reference
+    holds no proof bytes and cannot be run here: parity with real plonky2 stays unpinned) -- what it buys is that any drift
+    of the builder or the oracle is caught here on the CPU, and of the GPU prover by the same fixture in
+    test_gpu_parity.py::test_gpu_proofs_match_the_frozen_digests."""
+    import digest_cases as D
+    gold = D.fixture()
+    assert gold["zk_key"] == D.ZK_KEY
+    seen = 0
+    for name, (data, pws) in D.cases(pkg):
+        got = D.digest_case(orc, data, pws[0], name.startswith("zk_"))
+        assert got == gold["cases"][name], name
+        seen += 1
+    assert seen == len(gold["cases"]) == 7
