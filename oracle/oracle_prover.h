@@ -172,7 +172,7 @@ static inline OCircuit* load_circuit(const void* blob, size_t len) {
     char magic[8];
     r.get(magic, 8);
     if (memcmp(magic, "P2AESCIR", 8) != 0) throw std::runtime_error("oracle: bad magic");
-    if (r.g32() != 3) throw std::runtime_error("oracle: bad version");
+    if (r.g32() != 4) throw std::runtime_error("oracle: bad version");
     OCircuit* C = new OCircuit();
     r.get(&C->cfg, sizeof(OConfig));
     C->degree_bits = r.g32();

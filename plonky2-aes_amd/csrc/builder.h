@@ -2,8 +2,11 @@
 // (SURVEY.md Appendix A.1): add_virtual_target, constant/zero/one, arithmetic (mul_const_add, add, mul, sub,
 // mul_sub), select, is_equal, connect, add_lookup_table_from_pairs, add_lookup_from_index, num_gates, build.
 // Same names, argument meaning and constant-folding / op-caching / slot-packing behaviour as upstream, so the
-// gate rows a gadget produces here are the rows it produces there (gate ordering inside a partition of
-// copy-constrained wires -- i.e. the sigma cycle order -- is this file's own deterministic choice).
+// gate rows a gadget produces here are the rows it produces there.  Gate TYPES follow upstream's GateRef identity: every
+// lookup table has its own LookupGate and LookupTableGate type (their id() carries the table's Keccak hash), which decides
+// the number of selector polynomials; sigma sends each routed wire to the next wire of its copy class in (row, column)
+// order, as `wire_partition` / `get_sigma_map` do.  oracle/oracle_builder.py derives all of this a second time,
+// independently, and tests/test_independent_builder.py compares.
 //
 // Call sites mirrored: aes-gcm/src/circuit_aes.rs:176-358, aes-gcm/src/circuit_gcm.rs:49-425.
 #pragma once
@@ -15,6 +18,7 @@
 
 #include "circuit.h"
 #include "gl.h"
+#include "keccak.h"
 
 namespace p2 {
 
@@ -97,12 +101,14 @@ class CircuitBuilder {
         base_arithmetic_results_[key] = out;
         return out;
     }
-    Target mul_const_add(u64 c, Target x, Target y) { return arithmetic(c, 1, x, one(), y); }  // c*x + y
+    // c*x + y.  Upstream passes the constant one as the FIRST multiplicand here (`self.arithmetic(c, F::ONE, one, x, y)`), unlike
+    // add / sub where it is the second: which of the two multiplicand wires carries x is part of the circuit.
+    Target mul_const_add(u64 c, Target x, Target y) { return arithmetic(c, 1, one(), x, y); }
     Target add(Target x, Target y) { return arithmetic(1, 1, x, one(), y); }
     Target sub(Target x, Target y) { return arithmetic(1, gl::P - 1, x, one(), y); }
     Target mul(Target x, Target y) { return arithmetic(1, 0, x, y, x); }
     Target mul_sub(Target x, Target y, Target z) { return arithmetic(1, gl::P - 1, x, y, z); }  // x*y - z
-    Target mul_const(u64 c, Target x) { return arithmetic(c, 0, x, one(), zero()); }
+    Target mul_const(u64 c, Target x) { return mul_const_add(c, x, zero()); }
     // if b { x } else { y }
     Target select(BoolTarget b, Target x, Target y) {
         Target tmp = mul_sub(b.target, y, y);
@@ -362,14 +368,50 @@ inline Circuit CircuitBuilder::build() {
     while ((1ull << db) < n) db++;
     c.degree_bits = db;
 
-    // ---- gates, sorted by (degree, id); selector polynomials (plonky2 gates/selectors.rs) ----
-    bool present[G_NUM_KINDS] = {false};
-    for (auto& g : gate_instances_) present[g.kind] = true;
-    for (u32 k = 0; k < G_NUM_KINDS; k++)
-        if (present[k]) c.gates.push_back(k);
+    // ---- gate types, sorted by (degree, id) as `gates.sort_unstable_by_key(|g| (g.0.degree(), g.0.id()))`; selector
+    // polynomials (plonky2 gates/selectors.rs).  A LookupGate's id is "LookupGate {num_slots: 40, lut_hash: [..]}" and a
+    // LookupTableGate's "LookupTableGate {num_slots: 26, lut_hash: [..], last_lut_row: R}" with the table's Keccak-256 as a
+    // Rust {:?} byte list, so each table contributes two gate types of its own.
+    struct GateType {
+        u32 kind, lut;
+        std::string id;
+    };
+    std::vector<GateType> types;
+    {
+        bool present[G_NUM_KINDS] = {false};
+        for (auto& g : gate_instances_) present[g.kind] = true;
+        for (size_t l = 0; l < luts_.size(); l++) {
+            std::vector<uint8_t> bytes;
+            for (auto& pr : luts_[l])
+                for (u16 v : {pr.first, pr.second}) {
+                    bytes.push_back((uint8_t)(v & 0xFF));
+                    bytes.push_back((uint8_t)(v >> 8));
+                }
+            auto h = keccak256(bytes.data(), bytes.size());
+            std::string hs = "[";
+            for (size_t i = 0; i < h.size(); i++) hs += (i ? ", " : "") + std::to_string((unsigned)h[i]);
+            hs += "]";
+            types.push_back({G_LOOKUP, (u32)l, "LookupGate {num_slots: " + std::to_string(LU_SLOTS) + ", lut_hash: " + hs + "}"});
+            types.push_back({G_LOOKUP_TABLE, (u32)l,
+                             "LookupTableGate {num_slots: " + std::to_string(LUT_SLOTS) + ", lut_hash: " + hs + ", last_lut_row: " + std::to_string(lookup_rows_[l].last_lut) + "}"});
+        }
+        if (present[G_NOOP]) types.push_back({G_NOOP, 0, "NoopGate"});
+        if (present[G_CONSTANT]) types.push_back({G_CONSTANT, 0, "ConstantGate { num_consts: 2 }"});
+        if (present[G_PUBLIC_INPUT]) types.push_back({G_PUBLIC_INPUT, 0, "PublicInputGate"});
+        if (present[G_ARITHMETIC]) types.push_back({G_ARITHMETIC, 0, "ArithmeticGate { num_ops: 20 }"});
+        if (present[G_POSEIDON]) types.push_back({G_POSEIDON, 0, "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>"});
+        std::sort(types.begin(), types.end(), [](const GateType& a, const GateType& b) {
+            u32 da = gate_degree(a.kind), db = gate_degree(b.kind);
+            return da != db ? da < db : a.id < b.id;
+        });
+    }
+    for (auto& t : types) c.gates.push_back(t.kind);
     const u32 num_gates_kinds = (u32)c.gates.size();
-    std::vector<u32> kind_index(G_NUM_KINDS, 0);
-    for (u32 i = 0; i < num_gates_kinds; i++) kind_index[c.gates[i]] = i;
+    auto type_index = [&](const GateInstance& g) -> u32 {
+        for (u32 i = 0; i < num_gates_kinds; i++)
+            if (types[i].kind == g.kind && ((g.kind != G_LOOKUP && g.kind != G_LOOKUP_TABLE) || types[i].lut == (u32)g.constants[0])) return i;
+        throw std::runtime_error("gate instance without a gate type");
+    };
     const u32 max_degree = cfg_.quotient_degree_factor + 1;
     const u32 max_gate_degree = gate_degree(c.gates.back());
     if (max_gate_degree + num_gates_kinds - 1 <= max_degree) {
@@ -398,7 +440,7 @@ inline Circuit CircuitBuilder::build() {
     const u32 ncc = c.num_constants_cols();
     c.constants.assign((size_t)ncc * n, 0);
     for (size_t row = 0; row < n; row++) {
-        u32 gi = kind_index[gate_instances_[row].kind];
+        u32 gi = type_index(gate_instances_[row]);
         for (u32 s = 0; s < nsel; s++)
             c.constants[(size_t)s * n + row] = (nsel == 1 || c.selector_index[gi] == s) ? gi : UNUSED_SELECTOR;
         for (u32 k = 0; k < cfg_.num_constants; k++)
@@ -445,7 +487,9 @@ inline Circuit CircuitBuilder::build() {
         if (a != b) parent[std::max(a, b)] = std::min(a, b);
     }
 
-    // ---- sigma: next wire (column-major index order) inside each partition ----
+    // ---- sigma: every routed wire goes to the next wire of its partition in (row, column) order, the last to the first
+    // (plonk/permutation_argument.rs: `wire_partition` fills each class `for row { for column {..} }`, `get_sigma_map` links
+    // neighbours cyclically) ----
     c.k_is.resize(R);
     {
         u64 k = 1;
@@ -465,17 +509,18 @@ inline Circuit CircuitBuilder::build() {
     c.sigmas.resize((size_t)R * n);
     {
         const u32 NONE = 0xFFFFFFFFu;
-        std::vector<u32> first(N, NONE), last(N, NONE);
+        std::vector<u32> first(N, NONE), last(N, NONE);  // per class: column * n + row of its first / latest wire
         auto sig = [&](u64 from, u64 to) { c.sigmas[from] = gl::mul(c.k_is[to / n], subgroup[to % n]); };
-        for (u64 idx = 0; idx < (u64)R * n; idx++) {  // idx = col*n + row
-            u32 col = (u32)(idx / n), row = (u32)(idx % n);
-            u32 r = find((u32)(V + (u64)row * R + col));
-            if (first[r] == NONE)
-                first[r] = (u32)idx;
-            else
-                sig(last[r], idx);
-            last[r] = (u32)idx;
-        }
+        for (u32 row = 0; row < n; row++)
+            for (u32 col = 0; col < R; col++) {
+                const u32 idx = (u32)((u64)col * n + row);
+                u32 r = find((u32)(V + (u64)row * R + col));
+                if (first[r] == NONE)
+                    first[r] = idx;
+                else
+                    sig(last[r], idx);
+                last[r] = idx;
+            }
         for (u64 r = 0; r < N; r++)
             if (first[r] != NONE) sig(last[r], first[r]);
     }

@@ -74,6 +74,7 @@ static const u32 LU_SLOTS = 40;   // LookupGate::num_slots = num_routed_wires / 
 static const u32 LUT_SLOTS = 26;  // LookupTableGate::num_slots = num_routed_wires / 3
 static const u32 ARITH_OPS = 20;  // ArithmeticGate::num_ops = num_routed_wires / 4
 static const u32 UNUSED_SELECTOR = 0xFFFFFFFFu;
+static const u32 MAX_LUTS = 6, MAX_GATE_TYPES = 2 * MAX_LUTS + 5;  // per table: LookupGate + LookupTableGate; Noop, Constant, PublicInput, Arithmetic, Poseidon
 
 // Witness program: one op per generator, over "slots" (= copy-constraint partitions that carry a value).
 enum OpKind : u32 {
@@ -97,7 +98,8 @@ struct LookupRows {
 struct Circuit {
     Config cfg;
     u32 degree_bits = 0;
-    std::vector<u32> gates;                      // sorted gate kinds present in the circuit
+    std::vector<u32> gates;                      // kind of every gate TYPE in plonky2's (degree, id) order; one G_LOOKUP and one
+                                                 // G_LOOKUP_TABLE entry per lookup table (their ids carry the table's hash)
     std::vector<u32> selector_index;             // per gate: which selector polynomial
     std::vector<std::pair<u32, u32>> groups;     // per selector: [first gate, last gate)
     u32 num_lookup_selectors = 0;                // 0 or 4 + #luts
@@ -182,7 +184,7 @@ struct BlobReader {
 };
 
 static const char BLOB_MAGIC[8] = {'P', '2', 'A', 'E', 'S', 'C', 'I', 'R'};
-static const u32 BLOB_VERSION = 3;
+static const u32 BLOB_VERSION = 4;  // 4: one gate type per lookup table (repeated G_LOOKUP / G_LOOKUP_TABLE entries in `gates`), row-major sigma cycles
 
 static inline std::vector<uint8_t> serialize(const Circuit& c) {
     BlobWriter w;
@@ -236,7 +238,7 @@ static inline Circuit deserialize(const void* data, size_t len) {
     r.vec(c.sigmas);
     r.vec(c.k_is);
     u32 nl = r.r32();
-    if (nl > 6) throw std::runtime_error("too many lookup tables");
+    if (nl > MAX_LUTS) throw std::runtime_error("too many lookup tables");
     c.luts.resize(nl);
     for (auto& l : c.luts) r.vec(l);
     r.vec(c.lookup_rows);
@@ -251,9 +253,9 @@ static inline Circuit deserialize(const void* data, size_t len) {
     r.vec(c.blind_zrows);
     // shape checks: everything a kernel indexes with is validated here, once.
     size_t n = c.n();
-    if (c.gates.empty() || c.gates.size() > G_NUM_KINDS || c.groups.empty() || c.groups.size() > c.gates.size()) throw std::runtime_error("gate list");
+    if (c.gates.empty() || c.gates.size() > MAX_GATE_TYPES || c.groups.empty() || c.groups.size() > c.gates.size()) throw std::runtime_error("gate list");
     for (size_t i = 0; i < c.gates.size(); i++)
-        if (c.gates[i] >= G_NUM_KINDS || (i && c.gates[i] <= c.gates[i - 1])) throw std::runtime_error("gate kinds");
+        if (c.gates[i] >= G_NUM_KINDS || (i && (c.gates[i] < c.gates[i - 1] || (c.gates[i] == c.gates[i - 1] && c.gates[i] > G_LOOKUP_TABLE)))) throw std::runtime_error("gate kinds");
     for (auto& g : c.groups)
         if (g.first >= g.second || g.second > c.gates.size()) throw std::runtime_error("selector groups");
     for (size_t i = 0; i < c.selector_index.size(); i++)

@@ -20,7 +20,7 @@ struct QuotientArgs {
     size_t out_batch_stride;
     u32 n, logn, rate_bits, R, ncc, nsel, nls, NC, npp, qdf, num_luts, nsldc, lut_deg, nlp;
     u32 num_gates, num_gate_constraints;
-    u32 gate_kind[8], gate_sel[8], group_lo[8], group_hi[8];
+    u32 gate_kind[p2::MAX_GATE_TYPES], gate_sel[p2::MAX_GATE_TYPES], group_lo[p2::MAX_GATE_TYPES], group_hi[p2::MAX_GATE_TYPES];
     u32 lut_last_row[8];  // last_lut row per LUT: RE there equals get_lut_poly (read from the zs VALUES)
     const u64* zs_values;  // [zs_cols][n]
     size_t zs_values_batch_stride;

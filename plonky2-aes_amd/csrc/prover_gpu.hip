@@ -1024,7 +1024,7 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
         C->c = deserialize(blob, len);
         const Circuit& c = C->c;
         if (c.cfg.rate_bits != 3 || c.cfg.num_challenges != 2 || c.cfg.quotient_degree_factor != 8 || c.cfg.num_routed_wires != 80 || c.cfg.arity_bits != 4 ||
-            c.cfg.num_query_rounds > 64 || c.gates.size() > 8 || c.luts.size() > 6)
+            c.cfg.num_query_rounds > 64 || c.gates.size() > p2::MAX_GATE_TYPES || c.luts.size() > p2::MAX_LUTS)
             throw std::runtime_error("only CircuitConfig::standard_recursion_config() is supported");
         if (c.degree_bits > 22) throw std::runtime_error("degree_bits > 22 is not supported");
         C->device = device;

@@ -70,9 +70,12 @@ def test_circuit_shapes(pkg):
     # row counts of the reference's size-report configurations (circuit_gcm.rs:708-736 prints them, nothing is
     # recorded upstream; these are this repo's own regression values)
     data, _, _ = circuits.encrypt(pkg, 4, 1024, False)
-    assert data.info["degree_bits"] == 14 and data.info["num_luts"] == 3 and data.info["num_constants_cols"] == 10
+    assert data.info["degree_bits"] == 14 and data.info["num_luts"] == 3 and data.info["num_constants_cols"] == 11
+    # 3 tables x (LookupGate + LookupTableGate) + Noop + Constant + PublicInput + Arithmetic = 10 gate types: two selector
+    # polynomials ([0, 8) and [8, 10)), 5 + 3 lookup selectors, 2 gate constants
+    assert data.info["num_gate_kinds"] == 10
     assert data.info["num_zs_cols"] == 34 and data.info["num_quotient_cols"] == 16 and data.info["num_fri_rounds"] == 3
-    assert data.info["proof_bytes"] == 151132
+    assert data.info["proof_bytes"] == 151372
     data, _, _ = circuits.encrypt(pkg, 4, 13, True)
     assert data.info["degree_bits"] == 13 and data.info["num_luts"] == 5
     data, _ = circuits.assert_byte(pkg, [1])
