@@ -91,7 +91,11 @@ NOOP = GateType("noop", "NoopGate", 0, 0)
 CONSTANT = GateType("constant", "ConstantGate { num_consts: 2 }", 1, 2)
 PUBLIC_INPUT = GateType("public_input", "PublicInputGate", 1, 4)
 ARITHMETIC = GateType("arithmetic", "ArithmeticGate { num_ops: 20 }", 3, 20)
+POSEIDON = GateType("poseidon", "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>", 7, 123)
 LU_SLOTS, LUT_SLOTS, ARITH_OPS = NUM_ROUTED // 2, NUM_ROUTED // 3, NUM_ROUTED // 4
+# PoseidonGate wires (gates/poseidon.rs): 12 inputs | 12 outputs | swap | 4 deltas | S-box inputs of full rounds 1..3 | of the
+# 22 partial rounds | of the last 4 full rounds
+PG_IN, PG_OUT, PG_SWAP, PG_DELTA, PG_FULL0, PG_PARTIAL, PG_FULL1 = 0, 12, 24, 25, 29, 65, 87
 
 
 class Builder:
@@ -201,6 +205,28 @@ class Builder:
         self.connect(not_equal, diff_normalized)
         self.connect(not_equal_check, zero)
         return equal
+
+    # ---- gadgets/hash.rs, hash/poseidon.rs `permute_swapped` (swap = false), hash/hashing.rs `hash_n_to_m_no_pad`
+    def permute(self, state):
+        row = self.add_gate(POSEIDON)
+        self.connect(self.zero(), wire(row, PG_SWAP))
+        for i in range(12):
+            self.connect(state[i], wire(row, PG_IN + i))
+        self.generators.append(("poseidon", row))
+        return [wire(row, PG_OUT + i) for i in range(12)]
+
+    def hash_n_to_m_no_pad(self, inputs, num_outputs):
+        state = [self.zero()] * 12
+        for off in range(0, len(inputs), 8):
+            chunk = inputs[off:off + 8]
+            state = self.permute(chunk + state[len(chunk):])
+        out = []
+        while True:
+            for t in state[:8]:
+                out.append(t)
+                if len(out) == num_outputs:
+                    return out
+            state = self.permute(state)
 
     # ---- gadgets/lookup.rs
     def add_lookup_table_from_pairs(self, table):
@@ -357,8 +383,9 @@ class Shape:
 
     # ------------------------------------------------------------------------------------------- witness
     def witness(self, inputs):
-        """inputs: {virtual target: value}.  Returns wires[col][row] for the 80 routed columns (the AES circuits have no
-        advice wires), or raises ValueError the way plonky2's generators / copy-constraint check would fail."""
+        """inputs: {virtual target: value}.  Returns wires[col][row]: the 80 routed columns, or all 135 when the circuit has
+        PoseidonGate rows (the only gate here with advice wires).  Raises ValueError the way plonky2's generators / its
+        copy-constraint check would fail."""
         b, n, find, V = self.b, self.n, self.find, self.V
         val = {}
 
@@ -370,9 +397,14 @@ class Shape:
             setv(t, v % P)
         producers = {}                     # class -> generator (first one wins; the others only check)
         def outs(g):
+            if g[0] == "poseidon":         # every routed wire of the row except its inputs and swap
+                return [wire(g[1], c) for c in range(PG_OUT, NUM_ROUTED) if c != PG_SWAP]
             return {"arith": g[6:7], "equality": g[3:5], "lookup": g[3:4], "constant": g[1:2]}[g[0]]
         def ins(g):
+            if g[0] == "poseidon":
+                return [wire(g[1], PG_IN + i) for i in range(12)] + [wire(g[1], PG_SWAP)]
             return {"arith": g[3:6], "equality": g[1:3], "lookup": g[2:3], "constant": ()}[g[0]]
+        advice = {}                        # row -> the 135 wire values of a PoseidonGate row
         for g in b.generators:
             for o in outs(g):
                 producers.setdefault(find(self._node(o)), g)
@@ -383,6 +415,12 @@ class Shape:
             v = [val[find(self._node(t))] for t in ins(g)]
             if g[0] == "arith":
                 setv(g[6], (g[1] * v[0] * v[1] + g[2] * v[2]) % P)
+            elif g[0] == "poseidon":
+                full = poseidon_gate_row(v[:12], v[12])
+                for c in range(PG_OUT, NUM_ROUTED):
+                    if c != PG_SWAP:
+                        setv(wire(g[1], c), full[c])
+                advice[g[1]] = full
             elif g[0] == "constant":
                 setv(g[1], g[2])
             elif g[0] == "equality":
@@ -414,7 +452,10 @@ class Shape:
                 run(g)
                 done.add(id(g))
                 stack.pop()
-        wires = [[0] * n for _ in range(NUM_ROUTED)]
+        wires = [[0] * n for _ in range(NUM_WIRES if advice else NUM_ROUTED)]
+        for row, full in advice.items():
+            for c in range(NUM_ROUTED, NUM_WIRES):
+                wires[c][row] = full[c]
         for row in range(n):
             for col in range(NUM_ROUTED):
                 v = val.get(find(V + row * NUM_ROUTED + col))
@@ -436,6 +477,53 @@ class Shape:
                 row, s = first_lut - e // LUT_SLOTS, e % LUT_SLOTS
                 wires[3 * s][row], wires[3 * s + 1][row], wires[3 * s + 2][row] = inp, out, mult[e]
         return wires
+
+
+# ===================================================================================================== Poseidon
+def _round_constants():
+    import os
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "poseidon_rc.inc")).read()
+    rc = [int(h, 16) for h in re.findall(r"0x([0-9a-fA-F]{16})ULL", text)]
+    assert len(rc) == 360 and rc[0] == 0xB585F766F2144405            # upstream's first published constant
+    return rc
+
+
+MDS_CIRC, MDS_DIAG = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20], [8] + [0] * 11   # hash/poseidon_goldilocks.rs
+_RC = None
+
+
+def poseidon_gate_row(inputs, swap):
+    """PoseidonGenerator::run_once (gates/poseidon.rs): the 135 wires of one PoseidonGate row from its 12 inputs and swap."""
+    global _RC
+    _RC = _RC or _round_constants()
+    row = [0] * NUM_WIRES
+    row[PG_IN:PG_IN + 12], row[PG_SWAP] = inputs, swap
+    st = list(inputs)
+    for i in range(4):
+        row[PG_DELTA + i] = d = swap * (inputs[4 + i] - inputs[i]) % P
+        st[i], st[4 + i] = (inputs[i] + d) % P, (inputs[4 + i] - d) % P
+    for rnd in range(30):
+        st = [(x + _RC[12 * rnd + i]) % P for i, x in enumerate(st)]
+        if rnd < 4 or rnd >= 26:                                   # full rounds; the very first S-box layer is not witnessed
+            if rnd > 0:
+                base = PG_FULL0 + 12 * (rnd - 1) if rnd < 4 else PG_FULL1 + 12 * (rnd - 26)
+                row[base:base + 12] = st
+            st = [pow(x, 7, P) for x in st]
+        else:
+            row[PG_PARTIAL + rnd - 4] = st[0]
+            st[0] = pow(st[0], 7, P)
+        st = [(sum(st[(i + r) % 12] * MDS_CIRC[i] for i in range(12)) + st[r] * MDS_DIAG[r]) % P for r in range(12)]
+    row[PG_OUT:PG_OUT + 12] = st
+    return row
+
+
+def feistel_cipher(b, state, key_schedule, half=4):      # feistel/src/circuit.rs:42-70, f = hash_n_to_hash_no_pad (:126-131)
+    for k in key_schedule:
+        left, right = state[:half], state[half:]
+        offset = b.hash_n_to_m_no_pad(right + list(k), 4)
+        state = right + [b.add(left[i], offset[i]) for i in range(half)]
+    return state
 
 
 # ===================================================================================================== AES gadgets

@@ -132,3 +132,36 @@ def test_gpu_witness_equals_the_independent_derivation(pkg, orc, nk, L, tag):
         assert (got[:OB.NUM_ROUTED * shape.n].reshape(OB.NUM_ROUTED, shape.n) == want[i]).all()
         assert not got[OB.NUM_ROUTED * shape.n:].any()
         data.verify(proofs[i])
+
+
+def test_feistel_poseidon_circuit_equals_the_independent_derivation(pkg, orc):
+    """feistel/src/circuit.rs:115 (feistel_poseidon_check: 32 rounds, one PoseidonGate row each): gate types and selector
+    groups ([Noop, Constant, PublicInput, Arithmetic] | [Poseidon]), constants, sigma and all 135 wire columns, S-box input
+    advice wires included."""
+    data, pws = circuits.feistel_poseidon(pkg, [5])
+    B = Blob(data.blob)
+    ob = OB.Builder()
+    state_t = [ob.add_virtual_target() for _ in range(8)]
+    keys_t = [[ob.add_virtual_target() for _ in range(4)] for _ in range(32)]
+    out_t = OB.feistel_cipher(ob, state_t, keys_t)
+    shape = ob.build()
+    assert B.n == shape.n and [g.name for g in shape.gates] == ["noop", "constant", "public_input", "arithmetic", "poseidon"]
+    assert list(B.gates) == [2, 3, 4, 5, 6] and [tuple(g) for g in B.groups.tolist()] == shape.groups == [(0, 4), (4, 5)]
+    want = np.array(shape.constants, dtype=np.uint64)
+    assert want.shape == B.constants.shape and (want == B.constants).all()
+    assert (np.array(shape.sigma_values(), dtype=np.uint64).reshape(OB.NUM_ROUTED, shape.n) == B.sigmas).all()
+    # same inputs as circuits.feistel_poseidon(seed 5): the virtual targets were created in the same order on both sides
+    inputs = {t: v for t, v in pws[0].map.items() if t < len(state_t) + 4 * len(keys_t)}
+    assert len(inputs) == 8 + 128
+    st, wires = orc.OracleCircuit(data.blob).generate_witness(pws[0].map, OB.NUM_WIRES * shape.n)
+    assert st == 0
+    got = np.array(wires, dtype=np.uint64).reshape(OB.NUM_WIRES, shape.n)
+    want_wires = np.array(shape.witness(inputs), dtype=np.uint64)
+    assert want_wires.shape == got.shape and (want_wires == got).all()
+    # the cipher's output, read off the independent witness, is what the reference's native cipher gives (circuits.py checks
+    # the round trip lib.rs:98 on it)
+    outs = [v for t, v in pws[0].map.items() if t not in inputs]
+    assert len(outs) == 8
+    for t, v in zip(out_t, outs):
+        row, col = OB.wire_rc(t)
+        assert int(want_wires[col][row]) == v
