@@ -905,7 +905,7 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
     for (auto& d : wb.tree.cap()) w.digest(d);
     for (auto& d : zb.tree.cap()) w.digest(d);
     for (auto& d : qb.tree.cap()) w.digest(d);
-    for (auto* v : {&o_constants, &o_sigmas, &op_w, &o_zs, &o_zs_next, &o_pp, &op_q, &o_lk, &o_lk_next})
+    for (auto* v : {&o_constants, &o_sigmas, &op_w, &o_zs, &o_zs_next, &o_lk, &o_lk_next, &o_pp, &op_q})  // write_opening_set's order
         for (auto& e : *v) w.ext(e);
     for (auto& t : fri_trees)
         for (auto& d : t.cap()) w.digest(d);

@@ -1072,10 +1072,10 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
         range(ser, E_W, 0, W);
         range(ser, E_Z, 0, NC);
         range(ser, E_ZN, 0, NC);
+        range(ser, E_Z, nzpp, zc);   // write_opening_set puts lookup_zs / lookup_zs_next between plonk_zs_next and the
+        range(ser, E_ZN, nzpp, zc);  // partial products (the OpeningSet struct itself lists them last)
         range(ser, E_Z, NC, nzpp);
         range(ser, E_Q, 0, qc);
-        range(ser, E_Z, nzpp, zc);
-        range(ser, E_ZN, nzpp, zc);
         C->n_obs = (u32)obs.size();
         C->n_ser = (u32)ser.size();
         size_t fl = C->n;

@@ -158,8 +158,10 @@ inline std::string verify_proof(const Circuit& C, const VerifierData& vd, const 
     };
     auto wires_cap = read_cap(), zs_cap = read_cap(), quot_cap = read_cap();
     auto o_constants = read_exts(ncc), o_sigmas = read_exts(R), o_wires = read_exts(C.cfg.num_wires);
-    auto o_zs = read_exts(NC), o_zs_next = read_exts(NC), o_pp = read_exts(NC * npp), o_quot = read_exts(NC * qdf);
+    // read_opening_set: ..., plonk_zs, plonk_zs_next, lookup_zs, lookup_zs_next, partial_products, quotient_polys
+    auto o_zs = read_exts(NC), o_zs_next = read_exts(NC);
     auto o_lk = read_exts(NC * nlp), o_lk_next = read_exts(NC * nlp);
+    auto o_pp = read_exts(NC * npp), o_quot = read_exts(NC * qdf);
     std::vector<std::vector<Hash4>> fri_caps;
     for (size_t i = 0; i < arities.size(); i++) fri_caps.push_back(read_cap());
     struct Query {
