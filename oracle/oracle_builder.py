@@ -395,21 +395,17 @@ class Shape:
                 raise ValueError("conflicting values in one copy class")
         for t, v in inputs.items():
             setv(t, v % P)
-        producers = {}                     # class -> generator (first one wins; the others only check)
         def outs(g):
             if g[0] == "poseidon":         # every routed wire of the row except its inputs and swap
                 return [wire(g[1], c) for c in range(PG_OUT, NUM_ROUTED) if c != PG_SWAP]
             return {"arith": g[6:7], "equality": g[3:5], "lookup": g[3:4], "constant": g[1:2]}[g[0]]
+
         def ins(g):
             if g[0] == "poseidon":
                 return [wire(g[1], PG_IN + i) for i in range(12)] + [wire(g[1], PG_SWAP)]
             return {"arith": g[3:6], "equality": g[1:3], "lookup": g[2:3], "constant": ()}[g[0]]
         advice = {}                        # row -> the 135 wire values of a PoseidonGate row
-        for g in b.generators:
-            for o in outs(g):
-                producers.setdefault(find(self._node(o)), g)
         tables = [dict(t) for t in b.luts]
-        done = set()
 
         def run(g):
             v = [val[find(self._node(t))] for t in ins(g)]
@@ -431,27 +427,30 @@ class Shape:
                 if v[0] not in tables[g[1]]:
                     raise ValueError("lookup input is not in the table")
                 setv(g[3], tables[g[1]][v[0]])
-        for g0 in b.generators:            # depth-first over the dependency graph with an explicit stack
-            stack = [g0]
-            while stack:
-                g = stack[-1]
-                if id(g) in done:
-                    stack.pop()
-                    continue
-                need = []
-                for t in ins(g):
-                    r = find(self._node(t))
-                    if r not in val:
-                        p = producers.get(r)
-                        if p is None:
-                            raise ValueError("a generator input is never set")
-                        need.append(p)
-                if need:
-                    stack += need
-                    continue
-                run(g)
-                done.add(id(g))
-                stack.pop()
+        # iop/generator.rs `generate_partial_witness`: a generator runs once everything it watches is set (whichever
+        # generator or input set it); what it writes may wake others; whatever never runs leaves the witness incomplete
+        watchers, missing, ready = {}, [], []
+        for k, g in enumerate(b.generators):
+            unset = {find(self._node(t)) for t in ins(g)} - val.keys()
+            missing.append(len(unset))
+            for r in unset:
+                watchers.setdefault(r, []).append(k)
+            if not unset:
+                ready.append(k)
+        ran = 0
+        while ready:
+            g = b.generators[ready.pop()]
+            before = [find(self._node(o)) for o in outs(g)]
+            fresh = [r for r in before if r not in val]
+            run(g)
+            ran += 1
+            for r in dict.fromkeys(fresh):
+                for k in watchers.pop(r, ()):
+                    missing[k] -= 1
+                    if missing[k] == 0:
+                        ready.append(k)
+        if ran != len(b.generators):
+            raise ValueError("some generators never ran: the witness is incomplete")
         wires = [[0] * n for _ in range(NUM_WIRES if advice else NUM_ROUTED)]
         for row, full in advice.items():
             for c in range(NUM_ROUTED, NUM_WIRES):

@@ -165,3 +165,96 @@ def test_feistel_poseidon_circuit_equals_the_independent_derivation(pkg, orc):
     for t, v in zip(out_t, outs):
         row, col = OB.wire_rc(t)
         assert int(want_wires[col][row]) == v
+
+
+class _Dual:
+    """Drives the product's builder (through the C ABI) and the independent one with the same calls; a target is a pair."""
+
+    def __init__(self, pkg):
+        self.p, self.o = pkg.CircuitBuilder(), OB.Builder()
+
+    def __getattr__(self, name):
+        fp, fo = getattr(self.p, name), getattr(self.o, name)
+
+        def call(*args):
+            split = lambda k: [a[k] if isinstance(a, tuple) else ([x[k] for x in a] if isinstance(a, list) else a) for a in args]
+            rp, ro = fp(*split(0)), fo(*split(1))
+            if isinstance(rp, list):
+                return list(zip(rp, ro))
+            return None if rp is None else (rp, ro)
+        return call
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_circuits_compile_identically(pkg, orc, seed):
+    """Differential fuzz of the two builders over the whole generic vocabulary -- raw `arithmetic` with degenerate constants,
+    constant operands (every branch of `arithmetic_special_cases`), repeated operations (the result cache), add / sub / mul /
+    mul_const_add / select / is_equal / connect, lookups into one to three tables, Poseidon sponges -- then the same
+    comparison as for the AES circuits: gate count, gate types, selector groups, constants, sigma, and the witness."""
+    import random
+    r = random.Random(1000 + seed)
+    P = OB.P
+    d = _Dual(pkg)
+    tables = [[(i, (i * 7 + 3) & 0xFF) for i in range(256)], [(i, i >> 1) for i in range(256)], [((x << 3) + i, (x >> i) & 1) for x in range(32) for i in range(8)]]
+    luts = [(d.p.add_lookup_table_from_pairs(t), d.o.add_lookup_table_from_pairs(t)) for t in tables[:r.randrange(0, 4)]]
+    assert all(a == b for a, b in luts)
+    inputs = [d.add_virtual_target() for _ in range(r.randrange(2, 6))]
+    nodes = list(inputs) + [d.constant(c) for c in (0, 1, 2, P - 1, r.randrange(P))]
+    small = list(inputs)                           # targets whose value is inside every table's domain [0, 256)
+    used = set()
+    for _ in range(r.randrange(10, 120)):
+        kind = r.choice(["arith", "arith", "add", "sub", "mul", "mca", "select", "eq", "connect", "lookup", "lookup", "hash", "repeat"])
+        x, y, z = (r.choice(nodes) for _ in range(3))
+        if kind == "arith":
+            t = d.arithmetic(r.choice([0, 1, P - 1, 5, r.randrange(P)]), r.choice([0, 1, P - 1, r.randrange(P)]), x, y, z)
+        elif kind == "repeat":
+            t = d.arithmetic(1, 1, x, y, z)
+            assert d.arithmetic(1, 1, x, y, z) == t
+        elif kind in ("add", "sub", "mul"):
+            t = getattr(d, kind)(x, y)
+        elif kind == "mca":
+            t = d.mul_const_add(r.choice([1, 2, 256, P - 2, r.randrange(P)]), x, y)
+        elif kind == "select":
+            t = d.select(d.is_equal(x, y), z, x)
+        elif kind == "eq":
+            t = d.is_equal(x, y)
+        elif kind == "connect":
+            t = d.add(x, y)
+            d.connect(t, d.add(y, x))
+        elif kind == "lookup":
+            if not luts:
+                continue
+            k = r.randrange(len(luts))
+            t = d.add_lookup_from_index(r.choice(small) if r.random() < 0.9 else x, luts[k][0])
+            small.append(t)
+            used.add(k)
+        else:
+            outs = d.hash_n_to_m_no_pad([r.choice(nodes) for _ in range(r.randrange(1, 11))], r.randrange(1, 10))
+            nodes += outs
+            continue
+        nodes.append(t)
+    for k in range(len(luts)):                     # an unused table is an error in both builders: use each once
+        if k not in used:
+            d.add_lookup_from_index(inputs[0], luts[k][0])
+    assert d.p.num_gates() == d.o.num_gates()
+    data, shape = d.p.build(), d.o.build()
+    B = Blob(data.blob)
+    names = {"lookup": 0, "lookup_table": 1, "noop": 2, "constant": 3, "public_input": 4, "arithmetic": 5, "poseidon": 6}
+    assert B.n == shape.n and list(B.gates) == [names[g.name] for g in shape.gates]
+    assert [tuple(g) for g in B.groups.tolist()] == shape.groups
+    want = np.array(shape.constants, dtype=np.uint64)
+    assert want.shape == B.constants.shape and (want == B.constants).all()
+    assert (np.array(shape.sigma_values(), dtype=np.uint64).reshape(OB.NUM_ROUTED, shape.n) == B.sigmas).all()
+    assert [tuple(x) for x in B.lookup_rows.tolist()] == shape.b.lookup_rows
+    # witness on small inputs (so that lookups can hit); a circuit whose random structure is unsatisfiable must fail on both sides
+    vals = [r.randrange(32) for _ in inputs]
+    oc = orc.OracleCircuit(data.blob)
+    st, wires = oc.generate_witness({t[0]: v for t, v in zip(inputs, vals)}, OB.NUM_WIRES * shape.n)
+    try:
+        want_wires = np.array(shape.witness({t[1]: v for t, v in zip(inputs, vals)}), dtype=np.uint64)
+    except ValueError:
+        assert st != 0
+        return
+    assert st == 0
+    got = np.array(wires, dtype=np.uint64).reshape(OB.NUM_WIRES, shape.n)
+    assert (got[:want_wires.shape[0]] == want_wires).all() and not got[want_wires.shape[0]:].any()
