@@ -256,6 +256,26 @@ __device__ __forceinline__ void ntt_r16_stage(u64* x, const u64* w) {
         x[r + half] = gl::mul(gl::sub(u, v), w[base + r % half]);
     }
 }
+// the same at stride M = 1 (the last step): t' = 0, so the j = 0 twiddle of every stage is w^0 = 1 and its product is skipped
+// (15 of the step's 32 multiplications; the whole last stage)
+template <int A>
+__device__ __forceinline__ void ntt_r16_stage_m0(u64* x, const u64* w) {
+    constexpr int half = 8 >> A, base = 16 - 2 * half;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        if (r & half) continue;
+        const u64 u = x[r], v = x[r + half];
+        x[r] = gl::add(u, v);
+        x[r + half] = (r % half) ? gl::mul(gl::sub(u, v), w[base + r % half]) : gl::sub(u, v);
+    }
+}
+// LDS traffic between the lanes of ONE wave needs no s_barrier: a wave's LDS instructions execute in order; the fences keep
+// the compiler from moving the reads above the writes (it sees no alias: a lane reads what OTHER lanes wrote)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // SPLIT: one workgroup transforms HALF a column -- the first stage (h = n/2) is done while loading (every workgroup reads
 // both halves and keeps the sums or the twiddled differences), the remaining n/2-point transform runs in 70 KiB of LDS, so
 // that two workgroups share a compute unit and the load / store phases of one overlap the butterflies of the other.  (One
@@ -310,10 +330,89 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
             for (int k = 0; k < 16; k++) x[k] = gl::mul(x[k], pre[t + T * k]);
         }
     }
+    u64 w[15];
+    if (SPLIT) {
+        // Four stages straight from the load layout (stride T: h = n/2 .. n/16), ONE exchange across the workgroup, and from
+        // there on 2^(logn-4)-point transforms that each live inside one wave's 1024 points (thread t works on block
+        // t >> (logN - 4) of 2^logN points; 2^logN <= 1024 and blocks are aligned, so block and thread share t >> 6): every
+        // later exchange is between the lanes of a wave and costs no barrier, and the waves of a workgroup drift apart so
+        // that one's LDS and memory waits overlap another's butterflies.  (Round 2 first ran all four exchanges through
+        // __syncthreads: the waves were parked 55 % of the time.)
+        ntt_r16_load_tw(w, a.tw, t, logn - 4, a.log_nmax, 4);
+        ntt_r16_stage<0>(x, w);
+        ntt_r16_stage<1>(x, w);
+        ntt_r16_stage<2>(x, w);
+        ntt_r16_stage<3>(x, w);
+        int logN = logn - 4;                                   // stages left; 8 or 9 here (logn = 12, 13)
+        const int rem = (logN & 3) ? (logN & 3) : 4;
+        int m = logN - 4;
+        u32 tp = t & ((1u << m) - 1);
+        ntt_r16_load_tw(w, a.tw, tp, m, a.log_nmax, rem);      // in flight across the barrier
+        {
+            const NttLdsWalk wr(t, T);
+#pragma unroll
+            for (int r = 0; r < 16; r++) wr.at(lds, r) = x[r];
+        }
+        __syncthreads();
+        u32 base_idx = ((t >> m) << logN) | tp, stride = 1u << m;
+        {
+            const NttLdsWalk rd(base_idx, stride);
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = rd.at(lds, r);
+        }
+        ntt_r16_stage<0>(x, w);
+        if (rem >= 2) ntt_r16_stage<1>(x, w);
+        if (rem >= 3) ntt_r16_stage<2>(x, w);
+        if (rem >= 4) ntt_r16_stage<3>(x, w);
+        for (logN -= rem; logN >= 4; logN -= 4) {
+            m = logN - 4;
+            tp = t & ((1u << m) - 1);
+            ntt_r16_load_tw(w, a.tw, tp, m, a.log_nmax, 4);
+            {
+                const NttLdsWalk wr(base_idx, stride);
+#pragma unroll
+                for (int r = 0; r < 16; r++) wr.at(lds, r) = x[r];
+            }
+            wave_lds_sync();
+            base_idx = ((t >> m) << logN) | tp;
+            stride = 1u << m;
+            {
+                const NttLdsWalk rd(base_idx, stride);
+#pragma unroll
+                for (int r = 0; r < 16; r++) x[r] = rd.at(lds, r);
+            }
+            if (m == 0) {
+                ntt_r16_stage_m0<0>(x, w);
+                ntt_r16_stage_m0<1>(x, w);
+                ntt_r16_stage_m0<2>(x, w);
+                ntt_r16_stage_m0<3>(x, w);
+            } else {
+                ntt_r16_stage<0>(x, w);
+                ntt_r16_stage<1>(x, w);
+                ntt_r16_stage<2>(x, w);
+                ntt_r16_stage<3>(x, w);
+            }
+        }
+        {
+            const NttLdsWalk wr(base_idx, stride);
+#pragma unroll
+            for (int r = 0; r < 16; r++) wr.at(lds, r) = x[r];
+        }
+        wave_lds_sync();
+        // store order, still inside the wave: lane l of wave v takes points 1024 v + l + 64 k (512 contiguous bytes per store)
+        const u32 first = ((t >> 6) << 10) | (t & 63);
+        const NttLdsWalk fin(first, 64);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            u64 v = fin.at(lds, k);
+            if (a.post_scalar != 1) v = gl::mul(v, a.post_scalar);
+            out[first + 64 * k] = v;
+        }
+        return;
+    }
     // first step: the leading rem = logn mod 4 (or 4) stages on the whole array, stride M = n / 16
     // (with M = n / 16 stage A has h = n / 2^(A+1): these ARE the first `rem` stages of the whole transform)
     const int rem = (logn & 3) ? (logn & 3) : 4;
-    u64 w[15];
     ntt_r16_load_tw(w, a.tw, t, logn - 4, a.log_nmax, rem);
     ntt_r16_stage<0>(x, w);
     if (rem >= 2) ntt_r16_stage<1>(x, w);
@@ -339,10 +438,17 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
             for (int r = 0; r < 16; r++) x[r] = rd.at(lds, r);
         }
         // no barrier here: a thread writes back exactly the 16 locations it read, nobody else touches them in this step
-        ntt_r16_stage<0>(x, w);
-        ntt_r16_stage<1>(x, w);
-        ntt_r16_stage<2>(x, w);
-        ntt_r16_stage<3>(x, w);
+        if (m == 0) {
+            ntt_r16_stage_m0<0>(x, w);
+            ntt_r16_stage_m0<1>(x, w);
+            ntt_r16_stage_m0<2>(x, w);
+            ntt_r16_stage_m0<3>(x, w);
+        } else {
+            ntt_r16_stage<0>(x, w);
+            ntt_r16_stage<1>(x, w);
+            ntt_r16_stage<2>(x, w);
+            ntt_r16_stage<3>(x, w);
+        }
     }
     {
         const NttLdsWalk wr(base_idx, stride);
