@@ -134,6 +134,7 @@ struct NttArgs {
     u64* out;
     const u64* tw;     // w^k, k < n_max/2, for the forward or inverse root
     const u64* pre;    // [cosets][n] or null
+    const u64* pre_tw; // half-column form only, or null: [cosets][n/2] pre[coset][i] * tw(i), the coset scale folded into the first stage's twiddle
     const u64* post;   // [cosets][n] or null (indexed by natural output index; needs bitrev_out)
     u64 post_scalar;   // applied when post == null (1 = none)
     size_t in_col_stride, out_col_stride, in_batch_stride, out_batch_stride;
@@ -297,15 +298,29 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
     u64 x[16];
     if (SPLIT) {
         // stage h = n_full / 2 on the fly: sums feed the first half of the (bit-reversed) output, differences the second
+        if (pre) {
+            // pre[j] = s^j: u s^i +- v s^(i+n) = s^i (u +- S v) with S = s^n, so one uniform constant, one table value per
+            // point (s^i, or s^i w^i for the differences) and two multiplications instead of four loads and up to three
+            const u64 S = pre[n];
+            const u64* scale = half ? (a.pre_tw ? a.pre_tw + (size_t)coset * n : nullptr) : pre;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const u32 i = t + T * k;
-            u64 u = in[i], v = in[i + n];
-            if (pre) {
-                u = gl::mul(u, pre[i]);
-                v = gl::mul(v, pre[i + n]);
+            for (int k = 0; k < 16; k++) {
+                const u32 i = t + T * k;
+                const u64 u = in[i], v = gl::mul(in[i + n], S);
+                if (!half)
+                    x[k] = gl::mul(gl::add(u, v), scale[i]);
+                else if (scale)
+                    x[k] = gl::mul(gl::sub(u, v), scale[i]);
+                else
+                    x[k] = gl::mul(gl::mul(gl::sub(u, v), pre[i]), a.tw[(size_t)i << (a.log_nmax - a.logn)]);
             }
-            x[k] = half ? gl::mul(gl::sub(u, v), a.tw[(size_t)i << (a.log_nmax - a.logn)]) : gl::add(u, v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const u32 i = t + T * k;
+                const u64 u = in[i], v = in[i + n];
+                x[k] = half ? gl::mul(gl::sub(u, v), a.tw[(size_t)i << (a.log_nmax - a.logn)]) : gl::add(u, v);
+            }
         }
     } else if (a.bitrev_in) {
         // position i holds natural index rev(i): coalesced read, permute through LDS
@@ -536,6 +551,12 @@ __global__ void k_bitrev_copy(const u64* in, size_t in_col_stride, size_t in_bat
 }
 
 // table[j][i] = (base[j])^i  for i < n   (coset shift powers and their inverses, zeta powers, ...)
+// out[c][i] = a[c][i] * b[i << b_shift] for i < m (the LDE's coset scale folded into the first stage's twiddles)
+__global__ void k_mul_tables(u64* out, const u64* a, size_t a_stride, const u64* b, int b_shift, u32 m) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    out[(size_t)blockIdx.y * m + i] = gl::mul(a[(size_t)blockIdx.y * a_stride + i], b[(size_t)i << b_shift]);
+}
 __global__ void k_pow_table(u64* table, const u64* bases, u32 n, u64 scale) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

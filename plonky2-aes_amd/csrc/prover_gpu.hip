@@ -86,6 +86,7 @@ struct p2_circuit {
     u64 *d_tw_fwd_full = nullptr, *d_tw_inv_full = nullptr;  // w^k / w^-k for k < n (two-pass NTT, n > 2^14)
     u64* d_tw_fwd_round[9] = {nullptr};                       // order n_r tables for FRI rounds that still need two passes
     u64* d_shift_pows[9] = {nullptr};              // per FRI round r (0 = main LDE): [8][n_r] (s_r w^j)^i
+    u64* d_shift_tw = nullptr;                     // main LDE, 2^13 <= n <= 2^14: [8][n/2] d_shift_pows[0][j][i] * w^i
     u64* d_shift_inv_pows = nullptr;               // [8][n] (g w^j)^-i / n   (quotient inverse)
     u64 *d_xs = nullptr, *d_l0 = nullptr, *d_zh_inv = nullptr, *d_w8inv = nullptr, *d_qscale = nullptr;
     u64 *d_pre_coeffs = nullptr, *d_pre_lde = nullptr;
@@ -258,6 +259,7 @@ static int lde_cols(p2_circuit* C, const u64* coeffs, size_t in_batch_stride, u6
     a.out = lde;
     a.tw = C->d_tw_fwd;
     a.pre = C->d_shift_pows[round];
+    a.pre_tw = round == 0 ? C->d_shift_tw : nullptr;
     a.post_scalar = 1;
     a.in_col_stride = (size_t)1 << logn_r;
     a.out_col_stride = (size_t)8 << logn_r;
@@ -379,6 +381,10 @@ static int circuit_setup(p2_circuit* C) {
             if (upload(C, &d_b, bases.data(), 8)) return P2_ERR_HIP;
             if (dalloc(C, &C->d_shift_pows[r], 8 * n_r)) return P2_ERR_HIP;
             hipLaunchKernelGGL(k_pow_table, g1(n_r, 256, 8), dim3(256), 0, C->stream, C->d_shift_pows[r], d_b, (u32)n_r, (u64)1);
+            if (r == 0 && C->logn >= 13 && C->logn <= LDS_NTT_MAX_BITS) {
+                if (dalloc(C, &C->d_shift_tw, 8 * (n_r / 2))) return P2_ERR_HIP;
+                hipLaunchKernelGGL(k_mul_tables, g1(n_r / 2, 256, 8), dim3(256), 0, C->stream, C->d_shift_tw, C->d_shift_pows[0], n_r, C->d_tw_fwd, 0, (u32)(n_r / 2));
+            }
             if (r == 0) {
                 std::vector<u64> ib(8);
                 for (u32 j = 0; j < 8; j++) ib[j] = gl::inv(bases[j]);
