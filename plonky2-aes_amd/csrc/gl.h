@@ -45,6 +45,40 @@ GL_D u64 mad_co(u32 a, u32 b, u64 c, sg& k) {  // a * b + c, carry-out in k
     asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(k) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// The same with a UNIFORM multiplier kept in an SGPR (table constants fetched with scalar loads): an asm operand declared
+// "v" makes the compiler copy such a constant into a VGPR first, one v_mov per 32-bit half per use.  One scalar source per
+// VALU instruction is what gfx9-family encodings allow; inline constants (integers 0..64, -1) do not count.
+GL_D u64 mad_co_k(u32 k_uniform, u32 b, u64 c, sg& k) {
+    u64 r;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(k) : "s"(k_uniform), "v"(b), "v"(c));
+    return r;
+}
+// x * K + acc for a compile-time K in 0..64 (an inline constant): written as asm so that K = 2, 8, 16 stay multiplies -- the
+// compiler turns those into v_lshl_add_u64 on a zero-extended operand, which costs two moves to build and the same long slot
+template <u32 K>
+GL_D u64 madk(u32 x, u64 acc) {
+    static_assert(K <= 64, "not an inline constant");
+    u64 r;
+    sg dead;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(dead) : "v"(x), "n"(K), "v"(acc));
+    return r;
+}
+template <u32 K>
+GL_D u64 madk_s(u32 x, u64 acc_uniform) {  // the addend is a uniform 64-bit value in an SGPR pair (a round constant)
+    static_assert(K <= 64, "not an inline constant");
+    u64 r;
+    sg dead;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(dead) : "v"(x), "n"(K), "s"(acc_uniform));
+    return r;
+}
+template <u32 K>
+GL_D u64 madk0(u32 x) {
+    static_assert(K <= 64, "not an inline constant");
+    u64 r;
+    sg dead;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(dead) : "v"(x), "n"(K));
+    return r;
+}
 GL_D u64 mad_eps_co(u32 a, u64 c, sg& k) {  // a * (2^32 - 1) + c, carry-out in k
     u64 r;
     asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r), "=s"(k) : "v"(a), "v"(c));
@@ -104,14 +138,15 @@ GL_D u32 pick(sg m, u32 yes, u32 no) {  // per lane: m ? yes : no
 //   R = R - H.hi - k           (borrow B)      -- 2^96 = -1; k rides in as the borrow-in
 //   R += (C - B)(2^32 - 1)                     -- C - B in {-1, 0, 1}; neither correction can wrap again: after a carry
 //        R < (2^32-1)^2, so R - H.hi - k + 2^32 - 1 < 2^64; after a borrow alone R >= 2^64 - 2^32, so R - (2^32 - 1) > 0
-template <bool HAS_ADDEND>
+// A_UNIFORM: `a` is a uniform table constant (its halves stay in SGPRs; see mad_co_k)
+template <bool HAS_ADDEND, bool A_UNIFORM = false>
 GL_D u64 mulr_add_dev(u64 a, u64 b, u64 c) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u64 P = HAS_ADDEND ? (u64)a0 * b0 + (u32)c : (u64)a0 * b0;
     u64 Y = (u64)a0 * b1 + (P >> 32);
     if (HAS_ADDEND) Y = add_u32(Y, (u32)(c >> 32));
     sg k, C, b1_, B;
-    Y = mad_co(a1, b0, Y, k);
+    Y = A_UNIFORM ? mad_co_k(a1, b0, Y, k) : mad_co(a1, b0, Y, k);
     const u64 H = (u64)a1 * b1 + (Y >> 32);
     const u64 lo = (Y << 32) | (u32)P;
     const u64 R = mad_eps_co((u32)H, lo, C);

@@ -127,6 +127,27 @@ struct Acc {
         p = (u64)a1 * b0; t = o01 + p; co += t < p; o01 = t;
 #endif
     }
+    // the same with `k` a UNIFORM table constant (PF_E, PF_WHAT rows fetched by scalar loads): its halves are read straight
+    // from SGPRs -- every mad here has exactly one scalar source -- instead of being copied into VGPRs first
+    GL_HD void fma_k(u64 k, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const u32 a0 = (u32)k, a1 = (u32)(k >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+        unsigned long long s1, s2, s3, s4;
+        asm("v_mad_u64_u32 %[e01], %[s1], %[a0], %[b0], %[e01]\n\t"
+            "v_mad_u64_u32 %[o01], %[s2], %[a0], %[b1], %[o01]\n\t"
+            "v_mad_u64_u32 %[e23], %[s3], %[a1], %[b1], %[e23]\n\t"
+            "v_addc_co_u32_e64 %[ce0], %[s1], 0, %[ce0], %[s1]\n\t"
+            "v_mad_u64_u32 %[o01], %[s4], %[a1], %[b0], %[o01]\n\t"
+            "v_addc_co_u32_e64 %[co], %[s2], 0, %[co], %[s2]\n\t"
+            "v_addc_co_u32_e64 %[ce2], %[s3], 0, %[ce2], %[s3]\n\t"
+            "v_addc_co_u32_e64 %[co], %[s4], 0, %[co], %[s4]"
+            : [e01] "+v"(e01), [o01] "+v"(o01), [e23] "+v"(e23), [ce0] "+v"(ce0), [co] "+v"(co), [ce2] "+v"(ce2), [s1] "=&s"(s1), [s2] "=&s"(s2),
+              [s3] "=&s"(s3), [s4] "=&s"(s4)
+            : [a0] "s"(a0), [a1] "s"(a1), [b0] "v"(b0), [b1] "v"(b1));
+#else
+        fma(k, b);
+#endif
+    }
     // a < 2^32: only the two products with a's low half exist
     GL_HD void fma_small(u32 a0, u64 b) {
         u32 b0 = (u32)b, b1 = (u32)(b >> 32);
@@ -192,7 +213,11 @@ GL_HD u64 add_wrap(u64 a, u64 c) {
 //   the same issue time as the whole mad, valu_rates.hip), and its carry-out -- possible only when x1 >= 2^32 - 2^12 --
 //   is folded back by a second mad, which cannot wrap (the wrapped sum is < 2^44).
 GL_HD u64 fold_al_ah(u64 al, u64 ah) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u64 ah2 = gl::add_u32(ah, (u32)(al >> 32));  // through the multiplier: no zero-extension of al's high half
+#else
     const u64 ah2 = ah + (al >> 32);
+#endif
     const u32 x2 = (u32)(ah2 >> 32);
     const u64 base = (ah2 << 32) | (u32)al;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -216,6 +241,43 @@ GL_HD u64 fold_al_ah(u64 al, u64 ah) {
 //   out[r] = rc[r] + sum_i circ[i] * s[(i + r) % 12] + 8 * s[0] (r == 0)      as some u64 representative.
 // Evaluated on 32-bit halves: every accumulator stays below 2^43, one fold per output word.
 GL_HD void mds_full(u64* s, const unsigned long long* rc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Every term is one v_mad_u64_u32 with the coefficient as an inline constant (gl::madk: the coefficients 2, 8 and 16 must
+    // not become shift-adds on zero-extended operands), and the round constant is the ADDEND of the first one, read from its
+    // SGPR pair: no separate additions, no moves.
+    u32 l[12], h[12];
+    u64 res[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        l[i] = (u32)s[i];
+        h[i] = (u32)(s[i] >> 32);
+    }
+#define P2_MDS_TERM(i, K)                          \
+    al = gl::madk<K>(l[((i) + r) % 12], al);       \
+    ah = gl::madk<K>(h[((i) + r) % 12], ah);
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+        u64 al, ah;
+        if (rc) {
+            al = gl::madk_s<17>(l[r], (u64)(u32)rc[r]);
+            ah = gl::madk_s<17>(h[r], (u64)(rc[r] >> 32));
+        } else {
+            al = gl::madk0<17>(l[r]);
+            ah = gl::madk0<17>(h[r]);
+        }
+        P2_MDS_TERM(1, 15) P2_MDS_TERM(2, 41) P2_MDS_TERM(3, 16) P2_MDS_TERM(4, 2) P2_MDS_TERM(5, 28) P2_MDS_TERM(6, 13)
+        P2_MDS_TERM(7, 13) P2_MDS_TERM(8, 39) P2_MDS_TERM(9, 18) P2_MDS_TERM(10, 34) P2_MDS_TERM(11, 20)
+        if (r == 0) {
+            al = gl::madk<8>(l[0], al);
+            ah = gl::madk<8>(h[0], ah);
+        }
+        res[r] = fold_al_ah(al, ah);
+    }
+#undef P2_MDS_TERM
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = res[i];
+    return;
+#endif
     const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     u64 lo[12], hi[12], out[12];
 #pragma unroll
@@ -244,6 +306,18 @@ GL_HD void mds_full(u64* s, const unsigned long long* rc) {
 
 // Row 0 of the MDS alone: rc + sum_i circ[i] * s[i] + 8 * s[0]
 GL_HD u64 mds_row0(const u64* s, u64 rc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+        u64 al = gl::madk_s<17>((u32)s[0], (u64)(u32)rc), ah = gl::madk_s<17>((u32)(s[0] >> 32), rc >> 32);
+#define P2_MDS_TERM(i, K)                       \
+    al = gl::madk<K>((u32)s[i], al);            \
+    ah = gl::madk<K>((u32)(s[i] >> 32), ah);
+        P2_MDS_TERM(1, 15) P2_MDS_TERM(2, 41) P2_MDS_TERM(3, 16) P2_MDS_TERM(4, 2) P2_MDS_TERM(5, 28) P2_MDS_TERM(6, 13)
+        P2_MDS_TERM(7, 13) P2_MDS_TERM(8, 39) P2_MDS_TERM(9, 18) P2_MDS_TERM(10, 34) P2_MDS_TERM(11, 20) P2_MDS_TERM(0, 8)
+#undef P2_MDS_TERM
+        return fold_al_ah(al, ah);
+    }
+#endif
     const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     u64 al = (u32)rc, ah = rc >> 32;
 #pragma unroll
@@ -273,6 +347,15 @@ GL_HD u64 mulr_add(u64 a, u64 b, u64 c) {
 #endif
 }
 
+// the same with a uniform table constant as the first factor
+GL_HD u64 mulr_add_k(u64 k, u64 b, u64 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return gl::mulr_add_dev<true, true>(k, b, c);
+#else
+    return mulr_add(k, b, c);
+#endif
+}
+
 // In: canonical or not; out: canonical.
 GL_HD void poseidon(u64* s) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -296,7 +379,7 @@ GL_HD void poseidon(u64* s) {
             Acc a;
             a.init();
 #pragma unroll
-            for (int c = 0; c < 12; c++) a.fma(PF_E[r * 12 + c], z[c]);
+            for (int c = 0; c < 12; c++) a.fma_k(PF_E[r * 12 + c], z[c]);
             s[1 + r] = a.reduce();  // straight into the (dead) state: a separate result array costs 34 VGPRs and a wave of occupancy
         }
         s[0] = mds_row0(z, PF_A[0]);
@@ -308,11 +391,9 @@ GL_HD void poseidon(u64* s) {
         a.e01 = i < 21 ? PF_A[i + 1] : PF_RC26[0];  // the next S-box's / next full round's constant for lane 0
         a.fma_small(25, s0);
 #pragma unroll
-        for (int j = 0; j < 11; j++) a.fma(PF_WHAT[i * 11 + j], s[1 + j]);
+        for (int j = 0; j < 11; j++) a.fma_k(PF_WHAT[i * 11 + j], s[1 + j]);
 #pragma unroll
-        for (int j = 0; j < 11; j++) {
-            s[1 + j] = mulr_add(PF_V[i * 11 + j], s0, s[1 + j]);
-        }
+        for (int j = 0; j < 11; j++) s[1 + j] = mulr_add_k(PF_V[i * 11 + j], s0, s[1 + j]);
         s[0] = a.reduce();
     }
 #pragma unroll
