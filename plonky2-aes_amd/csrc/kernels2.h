@@ -51,8 +51,9 @@ struct AlphaAcc {
         pw[1] = apow_proof + APOW_STRIDE;
     }
     __device__ __forceinline__ void add(u32 idx, u64 term) {
-        acc[0].fma(term, pw[0][idx]);
-        acc[1].fma(term, pw[1][idx]);
+        // the powers are per proof (= per workgroup row blockIdx.y) and idx is never lane-dependent: uniform, read from SGPRs
+        acc[0].fma_k(pw[0][idx], term);
+        acc[1].fma_k(pw[1][idx], term);
     }
 };
 
