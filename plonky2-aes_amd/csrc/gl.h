@@ -130,6 +130,11 @@ GL_D u32 pick(sg m, u32 yes, u32 no) {  // per lane: m ? yes : no
     asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(no), "v"(yes), "s"(m));
     return r;
 }
+GL_D u32 one_where(sg m) {  // 1 in the lanes of mask m, 0 elsewhere
+    u32 r;
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(m));
+    return r;
+}
 // a * b + c mod p as SOME u64 (a, b, c arbitrary u64), 11 long + ~6 short issue slots (the textbook product followed by
 // reduce128 compiles to 15 + 6 without the addend):
 //   P = a0 b0 + c.lo;  Y = a0 b1 + P.hi + c.hi;  Y = a1 b0 + Y (carry k);  H = a1 b1 + Y.hi
@@ -152,11 +157,22 @@ GL_D u64 mulr_add_dev(u64 a, u64 b, u64 c) {
     const u64 R = mad_eps_co((u32)H, lo, C);
     const u32 r0 = subb_co((u32)R, (u32)(H >> 32), k, b1_);
     const u32 r1 = subb0_co((u32)(R >> 32), b1_, B);
-    const u32 dh = ones_where(B & ~C);            // - (2^32 - 1) = + {1, 0xFFFFFFFF}
-    const u32 dl = ones_where(C & ~B) - dh;       // + (2^32 - 1) = + {0xFFFFFFFF, 0}
-    u64 d = ((u64)dh << 32) | dl;
-    asm("" : "+v"(d));                            // keep the correction one 64-bit operand: one v_lshl_add_u64, not two
-    return (((u64)r1 << 32) | r0) + d;
+    const u64 Rs = ((u64)r1 << 32) | r0;
+    // A borrow needs R < H.hi + k <= 2^32 -- one product in 2^32 on random data, but exact zero limbs make it certain
+    // (2^48 * m 2^48 = m 2^96), so it must be handled; it is handled on a WAVE-UNIFORM branch: B is a lane mask in an SGPR
+    // pair, and when it is zero for the whole wave (the usual case) the correction is just + C (2^32 - 1), one 0/1 select and
+    // one mad (which cannot wrap: after a carry R < (2^32-1)^2).  2 long slots instead of 3 long + 1 short per product.
+    u64 Rs2 = Rs;
+    sg Cm = C;
+    if (__builtin_expect(B != 0, 0)) {            // if-then only: the lanes that borrowed without a carry get - (2^32 - 1)
+        const u32 dh = ones_where(B & ~C);        //   = + {1, 0xFFFFFFFF}; a borrow and a carry cancel
+        u64 d = ((u64)dh << 32) | (0u - dh);
+        asm("" : "+v"(d));                        // one 64-bit operand: one v_lshl_add_u64, not two adds
+        Rs2 = Rs + d;
+        Cm = C & ~B;
+    }
+    sg dead;
+    return mad_eps_co(one_where(Cm), Rs2, dead);
 }
 // any u64 -> the canonical representative: r - p = r + (2^32 - 1) (mod 2^64), and that add carries exactly when r >= p
 GL_D u64 canon_dev(u64 r) {

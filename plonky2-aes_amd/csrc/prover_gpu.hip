@@ -1470,6 +1470,18 @@ __global__ void k_selftest(unsigned long long* bad, u64 seed, size_t threads) {
         if (gl::mul_add(x, y, z) != gl::add_ref(gl::mul_ref(x, y), z)) b++;
         if (gl::add(x, y) != gl::add_ref(x, y) || gl::add(x, gl::P - 1) != gl::add_ref(x, gl::P - 1) || gl::add(y, gl::P - 1 - (y & 1)) != gl::add_ref(y, gl::P - 1 - (y & 1))) b++;
         if (glf::canon(hi) != hi % gl::P) b++;
+        // the reduction's borrow case (R < H.hi + k), which random inputs never reach: 2^48 * (m 2^48) = m 2^96 = -m, and
+        // 2^32 * (m 2^32) = m 2^64 with a zero low limb.  Odd threads keep random operands, so that one wave holds lanes that
+        // borrow next to lanes that carry (the correction is chosen per wave, then applied per lane).
+        {
+            const u64 mm = ((t * 64 + i) & 0xFFFE) + 1;
+            const u64 p48 = 1ull << 48, q = (t & 1) ? y : (mm << 48), pa = (t & 1) ? x : p48;
+            if (gl::mul(pa, q) != gl::mul_ref(pa, q)) b++;
+            if (glf::canon(glf::mulr(pa, q)) != gl::mul_ref(pa, q)) b++;
+            if (gl::mul_add(pa, q, z) != gl::add_ref(gl::mul_ref(pa, q), z)) b++;
+            const u64 e = (t & 2) ? (mm << 32) : (gl::P - mm), f = (t & 2) ? (1ull << 32) : (1ull << 48);
+            if (gl::mul(e, f) != gl::mul_ref(e, f)) b++;
+        }
     }
     u64 s0[12], s1[12];
     for (int k = 0; k < 12; k++) {
