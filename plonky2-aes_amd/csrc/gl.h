@@ -135,16 +135,43 @@ GL_D u32 one_where(sg m) {  // 1 in the lanes of mask m, 0 elsewhere
     asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(m));
     return r;
 }
+// Last step of a reduction.  Rs = R - (H.hi + k) is formed; C = carry of the mad that made R (worth + (2^32 - 1)), B = borrow of
+// the subtraction (worth - (2^32 - 1)); neither correction can wrap again: after a carry R < (2^32-1)^2, after a borrow alone
+// Rs >= 2^64 - 2^32.  A borrow needs R < H.hi + k <= 2^32 -- one product in 2^32 on random data, but exact zero limbs make it
+// certain (2^48 * m 2^48 = m 2^96) -- so it is handled, on a WAVE-UNIFORM branch: B is a lane mask in an SGPR pair, and when it
+// is zero for the whole wave (the usual case) what remains is + C (2^32 - 1): one 0/1 select and one mad, 2 long slots instead
+// of the 3 long + 1 short of a branch-free two-sided correction.
+// BRANCH = false keeps the branch-free two-sided correction: in the NTT kernels, whose waves wait on memory and LDS rather than
+// on issue slots, the compare-and-branch per product lengthened every wave's chain (LDE 20.9 -> 22.3 ms per chunk).
+template <bool BRANCH = true>
+GL_D u64 red_fix(u64 Rs, sg C, sg B) {
+    if (!BRANCH) {
+        const u32 dh = ones_where(B & ~C);        // - (2^32 - 1) = + {1, 0xFFFFFFFF}
+        const u32 dl = ones_where(C & ~B) - dh;   // + (2^32 - 1) = + {0xFFFFFFFF, 0}
+        u64 d = ((u64)dh << 32) | dl;
+        asm("" : "+v"(d));
+        return Rs + d;
+    }
+    sg Cm = C;
+    if (__builtin_expect(B != 0, 0)) {            // if-then only: the lanes that borrowed without a carry get - (2^32 - 1)
+        const u32 dh = ones_where(B & ~C);        //   = + {1, 0xFFFFFFFF}; a borrow and a carry cancel
+        u64 d = ((u64)dh << 32) | (0u - dh);
+        asm("" : "+v"(d));                        // one 64-bit operand: one v_lshl_add_u64, not two adds
+        Rs += d;
+        Cm = C & ~B;
+    }
+    sg dead;
+    return mad_eps_co(one_where(Cm), Rs, dead);
+}
 // a * b + c mod p as SOME u64 (a, b, c arbitrary u64), 11 long + ~6 short issue slots (the textbook product followed by
 // reduce128 compiles to 15 + 6 without the addend):
 //   P = a0 b0 + c.lo;  Y = a0 b1 + P.hi + c.hi;  Y = a1 b0 + Y (carry k);  H = a1 b1 + Y.hi
 //        exact: lo = (P.lo, Y.lo), hi = H + k 2^32; no intermediate can exceed 64 bits ((2^32-1)^2 + 2 (2^32-1) = 2^64 - 1)
 //   R = lo + H.lo (2^32 - 1)   (carry C)       -- 2^64 = 2^32 - 1: one mad
 //   R = R - H.hi - k           (borrow B)      -- 2^96 = -1; k rides in as the borrow-in
-//   R += (C - B)(2^32 - 1)                     -- C - B in {-1, 0, 1}; neither correction can wrap again: after a carry
-//        R < (2^32-1)^2, so R - H.hi - k + 2^32 - 1 < 2^64; after a borrow alone R >= 2^64 - 2^32, so R - (2^32 - 1) > 0
+//   R += (C - B)(2^32 - 1)                     -- red_fix
 // A_UNIFORM: `a` is a uniform table constant (its halves stay in SGPRs; see mad_co_k)
-template <bool HAS_ADDEND, bool A_UNIFORM = false>
+template <bool HAS_ADDEND, bool A_UNIFORM = false, bool BRANCH = true>
 GL_D u64 mulr_add_dev(u64 a, u64 b, u64 c) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u64 P = HAS_ADDEND ? (u64)a0 * b0 + (u32)c : (u64)a0 * b0;
@@ -157,22 +184,15 @@ GL_D u64 mulr_add_dev(u64 a, u64 b, u64 c) {
     const u64 R = mad_eps_co((u32)H, lo, C);
     const u32 r0 = subb_co((u32)R, (u32)(H >> 32), k, b1_);
     const u32 r1 = subb0_co((u32)(R >> 32), b1_, B);
-    const u64 Rs = ((u64)r1 << 32) | r0;
-    // A borrow needs R < H.hi + k <= 2^32 -- one product in 2^32 on random data, but exact zero limbs make it certain
-    // (2^48 * m 2^48 = m 2^96), so it must be handled; it is handled on a WAVE-UNIFORM branch: B is a lane mask in an SGPR
-    // pair, and when it is zero for the whole wave (the usual case) the correction is just + C (2^32 - 1), one 0/1 select and
-    // one mad (which cannot wrap: after a carry R < (2^32-1)^2).  2 long slots instead of 3 long + 1 short per product.
-    u64 Rs2 = Rs;
-    sg Cm = C;
-    if (__builtin_expect(B != 0, 0)) {            // if-then only: the lanes that borrowed without a carry get - (2^32 - 1)
-        const u32 dh = ones_where(B & ~C);        //   = + {1, 0xFFFFFFFF}; a borrow and a carry cancel
-        u64 d = ((u64)dh << 32) | (0u - dh);
-        asm("" : "+v"(d));                        // one 64-bit operand: one v_lshl_add_u64, not two adds
-        Rs2 = Rs + d;
-        Cm = C & ~B;
-    }
-    sg dead;
-    return mad_eps_co(one_where(Cm), Rs2, dead);
+    return red_fix<BRANCH>(((u64)r1 << 32) | r0, C, B);
+}
+// hi * 2^64 + lo -> some u64 congruent to it: the same reduction for a 128-bit value that is already there (Acc::reduce)
+GL_D u64 red128_dev(u64 hi, u64 lo) {
+    sg C, b1_, B;
+    const u64 R = mad_eps_co((u32)hi, lo, C);
+    const u32 r0 = sub_co((u32)R, (u32)(hi >> 32), b1_);
+    const u32 r1 = subb0_co((u32)(R >> 32), b1_, B);
+    return red_fix(((u64)r1 << 32) | r0, C, B);
 }
 // any u64 -> the canonical representative: r - p = r + (2^32 - 1) (mod 2^64), and that add carries exactly when r >= p
 GL_D u64 canon_dev(u64 r) {
@@ -252,6 +272,14 @@ GL_HD u64 mul_ref(u64 a, u64 b) {  // textbook form: the host path, and what the
 GL_HD u64 mul(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return canon_dev(mulr_add_dev<false>(a, b, 0));
+#else
+    return mul_ref(a, b);
+#endif
+}
+// the NTT kernels' multiply (see red_fix)
+GL_HD u64 mul_nb(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return canon_dev(mulr_add_dev<false, false, false>(a, b, 0));
 #else
     return mul_ref(a, b);
 #endif

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(1024) void k_ntt_lds(NttArgs a) {
     for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
         u64 v = in[i];  // coalesced read; the permutation happens on the LDS side
         u32 dst = a.bitrev_in ? (__brev(i) >> (32 - logn)) : i;
-        if (pre) v = gl::mul(v, pre[dst]);
+        if (pre) v = gl::mul_nb(v, pre[dst]);
         lds[dst] = v;
     }
     __syncthreads();
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(1024) void k_ntt_lds(NttArgs a) {
             u64 x = lds[i], y = lds[i + h];
             u64 w = a.tw[(size_t)(pos << (logn - 1 - s)) << tw_shift];
             lds[i] = gl::add(x, y);
-            lds[i + h] = gl::mul(gl::sub(x, y), w);
+            lds[i + h] = gl::mul_nb(gl::sub(x, y), w);
         }
         __syncthreads();
         s--;
@@ -187,14 +187,14 @@ __global__ __launch_bounds__(1024) void k_ntt_lds(NttArgs a) {
             // stage s: twiddle w_{2h}^(i mod h); here i mod h = pos and (i+q) mod h = pos + q
             u64 w0 = a.tw[(size_t)(pos << (logn - 1 - s)) << tw_shift];
             u64 w1 = a.tw[(size_t)((pos + q) << (logn - 1 - s)) << tw_shift];
-            u64 b0 = gl::add(a0, a2), b2 = gl::mul(gl::sub(a0, a2), w0);
-            u64 b1 = gl::add(a1, a3), b3 = gl::mul(gl::sub(a1, a3), w1);
+            u64 b0 = gl::add(a0, a2), b2 = gl::mul_nb(gl::sub(a0, a2), w0);
+            u64 b1 = gl::add(a1, a3), b3 = gl::mul_nb(gl::sub(a1, a3), w1);
             // stage s-1: twiddle w_{2q}^(i mod q), the same for both pairs
             u64 w2 = a.tw[(size_t)(pos << (logn - s)) << tw_shift];
             lds[i] = gl::add(b0, b1);
-            lds[i + q] = gl::mul(gl::sub(b0, b1), w2);
+            lds[i + q] = gl::mul_nb(gl::sub(b0, b1), w2);
             lds[i + h] = gl::add(b2, b3);
-            lds[i + h + q] = gl::mul(gl::sub(b2, b3), w2);
+            lds[i + h + q] = gl::mul_nb(gl::sub(b2, b3), w2);
         }
         __syncthreads();
     }
@@ -203,9 +203,9 @@ __global__ __launch_bounds__(1024) void k_ntt_lds(NttArgs a) {
         u32 src = a.bitrev_out ? (__brev(i) >> (32 - logn)) : i;
         u64 v = lds[src];
         if (post)
-            v = gl::mul(v, post[i]);
+            v = gl::mul_nb(v, post[i]);
         else if (a.post_scalar != 1)
-            v = gl::mul(v, a.post_scalar);
+            v = gl::mul_nb(v, a.post_scalar);
         out[i] = v;
     }
 }
@@ -254,7 +254,7 @@ __device__ __forceinline__ void ntt_r16_stage(u64* x, const u64* w) {
         if (r & half) continue;
         const u64 u = x[r], v = x[r + half];
         x[r] = gl::add(u, v);
-        x[r + half] = gl::mul(gl::sub(u, v), w[base + r % half]);
+        x[r + half] = gl::mul_nb(gl::sub(u, v), w[base + r % half]);
     }
 }
 // the same at stride M = 1 (the last step): t' = 0, so the j = 0 twiddle of every stage is w^0 = 1 and its product is skipped
@@ -267,7 +267,7 @@ __device__ __forceinline__ void ntt_r16_stage_m0(u64* x, const u64* w) {
         if (r & half) continue;
         const u64 u = x[r], v = x[r + half];
         x[r] = gl::add(u, v);
-        x[r + half] = (r % half) ? gl::mul(gl::sub(u, v), w[base + r % half]) : gl::sub(u, v);
+        x[r + half] = (r % half) ? gl::mul_nb(gl::sub(u, v), w[base + r % half]) : gl::sub(u, v);
     }
 }
 // LDS traffic between the lanes of ONE wave needs no s_barrier: a wave's LDS instructions execute in order; the fences keep
@@ -306,20 +306,20 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const u32 i = t + T * k;
-                const u64 u = in[i], v = gl::mul(in[i + n], S);
+                const u64 u = in[i], v = gl::mul_nb(in[i + n], S);
                 if (!half)
-                    x[k] = gl::mul(gl::add(u, v), scale[i]);
+                    x[k] = gl::mul_nb(gl::add(u, v), scale[i]);
                 else if (scale)
-                    x[k] = gl::mul(gl::sub(u, v), scale[i]);
+                    x[k] = gl::mul_nb(gl::sub(u, v), scale[i]);
                 else
-                    x[k] = gl::mul(gl::mul(gl::sub(u, v), pre[i]), a.tw[(size_t)i << (a.log_nmax - a.logn)]);
+                    x[k] = gl::mul_nb(gl::mul_nb(gl::sub(u, v), pre[i]), a.tw[(size_t)i << (a.log_nmax - a.logn)]);
             }
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const u32 i = t + T * k;
                 const u64 u = in[i], v = in[i + n];
-                x[k] = half ? gl::mul(gl::sub(u, v), a.tw[(size_t)i << (a.log_nmax - a.logn)]) : gl::add(u, v);
+                x[k] = half ? gl::mul_nb(gl::sub(u, v), a.tw[(size_t)i << (a.log_nmax - a.logn)]) : gl::add(u, v);
             }
         }
     } else if (a.bitrev_in) {
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
         for (int k = 0; k < 16; k++) {
             const u32 i = t + T * k, dst = __brev(i) >> (32 - logn);
             u64 v = in[i];
-            if (pre) v = gl::mul(v, pre[dst]);
+            if (pre) v = gl::mul_nb(v, pre[dst]);
             lds[ntt_pad(dst)] = v;
         }
         __syncthreads();
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
         for (int k = 0; k < 16; k++) x[k] = in[t + T * k];
         if (pre) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = gl::mul(x[k], pre[t + T * k]);
+            for (int k = 0; k < 16; k++) x[k] = gl::mul_nb(x[k], pre[t + T * k]);
         }
     }
     u64 w[15];
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             u64 v = fin.at(lds, k);
-            if (a.post_scalar != 1) v = gl::mul(v, a.post_scalar);
+            if (a.post_scalar != 1) v = gl::mul_nb(v, a.post_scalar);
             out[first + 64 * k] = v;
         }
         return;
@@ -477,9 +477,9 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
         const u32 i = t + T * k;
         u64 v = (!SPLIT && a.bitrev_out) ? lds[ntt_pad(__brev(i) >> (32 - logn))] : fin.at(lds, k);
         if (post)
-            v = gl::mul(v, post[(size_t)half * n + i]);
+            v = gl::mul_nb(v, post[(size_t)half * n + i]);
         else if (a.post_scalar != 1)
-            v = gl::mul(v, a.post_scalar);
+            v = gl::mul_nb(v, a.post_scalar);
         out[i] = v;
     }
 }
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass1(Pass1Args a) {
         u32 j1 = e >> a.log_T, t = e & (T - 1);
         size_t idx = (size_t)j1 * n2 + j2_0 + t;
         u64 v = in[idx];
-        if (pre) v = gl::mul(v, pre[idx]);
+        if (pre) v = gl::mul_nb(v, pre[idx]);
         lds[e] = v;
     }
     __syncthreads();
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass1(Pass1Args a) {
             u64 x = lds[(i << a.log_T) + t], y = lds[((i + h) << a.log_T) + t];
             u64 w = a.tw[(size_t)(pos << (a.log_n1 - 1 - s)) << log_n2];  // w_n1^(pos * 2^(log_n1-1-s))
             lds[(i << a.log_T) + t] = gl::add(x, y);
-            lds[((i + h) << a.log_T) + t] = gl::mul(gl::sub(x, y), w);
+            lds[((i + h) << a.log_T) + t] = gl::mul_nb(gl::sub(x, y), w);
         }
         __syncthreads();
     }
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass1(Pass1Args a) {
         u32 r = e >> a.log_T, t = e & (T - 1);
         u32 k1 = a.log_n1 ? (__brev(r) >> (32 - a.log_n1)) : 0;
         u32 j2 = j2_0 + t;
-        out[(size_t)r * n2 + j2] = gl::mul(lds[e], a.tw[(size_t)k1 * j2]);
+        out[(size_t)r * n2 + j2] = gl::mul_nb(lds[e], a.tw[(size_t)k1 * j2]);
     }
 }
 // out[i] = in[rev(i)] (* post[row][i]) on `blocks` consecutive blocks of n per column

@@ -48,6 +48,9 @@ GL_HD void mul128(u64 a, u64 b, u64& hi, u64& lo) {
 // The result T - net * p lies in [0, 2^64) for every input (checked against 128-bit arithmetic on 2*10^8 inputs and all
 // combinations of extreme halves).
 GL_HD u64 red128(u64 hi, u64 lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return gl::red128_dev(hi, lo);  // one mad, two subtracts, the wave-uniform correction (gl.h)
+#endif
     const u32 l0 = (u32)lo, l1 = (u32)(lo >> 32), hl = (u32)hi, hh = (u32)(hi >> 32);
     u32 C, cv, b, B;
     const u32 u1 = __builtin_addc(l1, hl, 0u, &C);   // lo + (hl << 32): carry C
@@ -221,15 +224,10 @@ GL_HD u64 fold_al_ah(u64 al, u64 ah) {
     const u32 x2 = (u32)(ah2 >> 32);
     const u64 base = (ah2 << 32) | (u32)al;
 #if defined(__HIP_DEVICE_COMPILE__)
-    u64 r;
-    u32 cv;
-    unsigned long long sc, sc2;
-    asm("v_mad_u64_u32 %[r], %[sc], %[x2], -1, %[base]\n\t"
-        "s_nop 1\n\t"
-        "v_addc_co_u32_e64 %[cv], %[sc], 0, 0, %[sc]\n\t"
-        "v_mad_u64_u32 %[r], %[sc2], %[cv], -1, %[r]"
-        : [r] "=&v"(r), [cv] "=&v"(cv), [sc] "=&s"(sc), [sc2] "=&s"(sc2)
-        : [x2] "v"(x2), [base] "v"(base));
+    // the carry needs x1 >= 2^32 - 2^12: once in 2^20 on random data, so its fold sits behind a wave-uniform branch
+    gl::sg sc, dead;
+    u64 r = gl::mad_eps_co(x2, base, sc);
+    if (__builtin_expect(sc != 0, 0)) r = gl::mad_eps_co(gl::one_where(sc), r, dead);
     return r;
 #else
     const u64 t = base + (u64)x2 * gl::EPS;
