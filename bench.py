@@ -295,7 +295,7 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(avg_ms, 4),
                         "share_of_gpu_time": round(ms / total, 3),
-                        "note": "kernel is VALU-issue bound (a Poseidon permutation is 17.2 k VALU instructions), not HBM bound: see roofline_valu and DESIGN.md section 5",
+                        "note": "kernel is VALU-issue bound (a Poseidon permutation is 15.5 k VALU instructions), not HBM bound: see roofline_valu and DESIGN.md section 5",
                         "poseidon_perm_per_s": round((24 * (8 << info["degree_bits"]) * chunk / 3.0) / (avg_ms * 1e-3)) if dom == "hash_leaves" else None}
         # The roofline that actually bounds the path: VALU issue.  Instruction counts per launch are a property of the
         # kernel and the workload (rocprofv3 --pmc SQ_INSTS_VALU, profiles/<tag>_valu.json via tools/pmc_valu.py); the
