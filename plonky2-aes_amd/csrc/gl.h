@@ -115,6 +115,25 @@ GL_D u32 subb_co(u32 x, u32 y, sg cin, sg& cout) {  // x - y - cin, borrow-out i
     asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r), "=s"(cout) : "v"(x), "v"(y), "s"(cin));
     return r;
 }
+// the same WITHOUT the leading wait states: only where the data flow guarantees that at least two instructions of this wave
+// issue between the VALU write of `cin` and this read (in mulr_add_dev the carry k of the third product is read after the fourth
+// product, two moves and the reduction's mad, all of which depend on it)
+GL_D u32 subb_co_settled(u32 x, u32 y, sg cin, sg& cout) {
+    u32 r;
+    asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r), "=s"(cout) : "v"(x), "v"(y), "s"(cin));
+    return r;
+}
+// Rs + (lanes of C ? 2^32 - 1 : 0), C settled (written at least two instructions earlier): a 0/1 select and one mad, one block
+GL_D u64 add_eps_where_settled(sg C, u64 Rs) {
+    u64 out;
+    u32 c01;
+    sg dead;
+    asm("v_cndmask_b32_e64 %[c], 0, 1, %[m]\n\t"
+        "v_mad_u64_u32 %[o], %[d], %[c], -1, %[r]"
+        : [o] "=&v"(out), [c] "=&v"(c01), [d] "=&s"(dead)
+        : [m] "s"(C), [r] "v"(Rs));
+    return out;
+}
 GL_D u32 subb0_co(u32 x, sg cin, sg& cout) {  // x - cin, borrow-out in cout
     u32 r;
     asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(cout) : "v"(x), "s"(cin));
@@ -160,8 +179,25 @@ GL_D u64 red_fix(u64 Rs, sg C, sg B) {
         Rs += d;
         Cm = C & ~B;
     }
-    sg dead;
-    return mad_eps_co(one_where(Cm), Rs, dead);
+    // C was written by the reduction's mad, two subtract instructions (and their wait states) ago; Cm on the rare path by SALU
+    return add_eps_where_settled(Cm, Rs);
+}
+// per lane m ? yes : no on both halves of a 64-bit value, one block: the two wait states after the VALU write of m are paid once
+GL_D u64 pick64(sg m, u64 yes, u64 no) {
+    u32 lo, hi;
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %3, %2, %6\n\tv_cndmask_b32_e64 %1, %5, %4, %6"
+        : "=&v"(lo), "=&v"(hi)
+        : "v"((u32)yes), "v"((u32)no), "v"((u32)(yes >> 32)), "v"((u32)(no >> 32)), "s"(m));
+    return ((u64)hi << 32) | lo;
+}
+// the same for a mask that the SCALAR unit produced (an s_or / s_and of carry masks): no wait states -- the compiler itself
+// issues v_cndmask right behind such an instruction
+GL_D u64 pick64_salu(sg m, u64 yes, u64 no) {
+    u32 lo, hi;
+    asm("v_cndmask_b32_e64 %0, %3, %2, %6\n\tv_cndmask_b32_e64 %1, %5, %4, %6"
+        : "=&v"(lo), "=&v"(hi)
+        : "v"((u32)yes), "v"((u32)no), "v"((u32)(yes >> 32)), "v"((u32)(no >> 32)), "s"(m));
+    return ((u64)hi << 32) | lo;
 }
 // a * b + c mod p as SOME u64 (a, b, c arbitrary u64), 11 long + ~6 short issue slots (the textbook product followed by
 // reduce128 compiles to 15 + 6 without the addend):
@@ -182,7 +218,7 @@ GL_D u64 mulr_add_dev(u64 a, u64 b, u64 c) {
     const u64 H = (u64)a1 * b1 + (Y >> 32);
     const u64 lo = (Y << 32) | (u32)P;
     const u64 R = mad_eps_co((u32)H, lo, C);
-    const u32 r0 = subb_co((u32)R, (u32)(H >> 32), k, b1_);
+    const u32 r0 = subb_co_settled((u32)R, (u32)(H >> 32), k, b1_);
     const u32 r1 = subb0_co((u32)(R >> 32), b1_, B);
     return red_fix<BRANCH>(((u64)r1 << 32) | r0, C, B);
 }
@@ -198,7 +234,7 @@ GL_D u64 red128_dev(u64 hi, u64 lo) {
 GL_D u64 canon_dev(u64 r) {
     sg c;
     const u64 t = add_eps_co(r, c);
-    return ((u64)pick(c, (u32)(t >> 32), (u32)(r >> 32)) << 32) | pick(c, (u32)t, (u32)r);
+    return pick64(c, t, r);
 }
 #endif
 
@@ -210,8 +246,8 @@ GL_HD u64 add(u64 a, u64 b) {
     const u32 s0 = add_co((u32)a, (u32)b, k);
     const u32 s1 = addc_co((u32)(a >> 32), (u32)(b >> 32), k, c1);
     const u64 t = add_eps_co(((u64)s1 << 32) | s0, c2);
-    const sg m = c1 | c2;
-    return ((u64)pick(m, (u32)(t >> 32), s1) << 32) | pick(m, (u32)t, s0);
+    const sg m = c1 | c2;  // a uniform 64-bit OR: the compiler emits s_or_b64 (an asm s_or_b64 would clobber SCC behind its back)
+    return pick64_salu(m, t, ((u64)s1 << 32) | s0);
 #else
     u64 s = a + b;
     // a,b < p so a+b < 2p < 2^65; overflow or s>=p => subtract p once.
