@@ -36,8 +36,12 @@ static const u64 W_EXT = 7;                          // x^2 = 7
 // three-source ops, v_lshl_add_u64 -- 4.1 (and v_cndmask_b32 on VCC 23).  So a v_mad_u64_u32 is a 64-bit adder with a free
 // multiplier and a carry-out, and the field operations below are built from it rather than from compare-and-select.
 // A wave-wide carry lives in an SGPR pair (`sg`).  gfx950 needs two wait states between a VALU write of an SGPR and a
-// VALU read of it, and the compiler's hazard recogniser does not look inside inline asm: every helper that READS a carry
-// starts with s_nop 1 (a nop delays only its own wave; the SIMD issues from the other resident waves meanwhile).
+// VALU read of it, and the compiler's hazard recogniser does not look inside inline asm: a helper that READS a carry starts
+// with s_nop 1 -- unless its name ends in _settled (the caller's data flow puts two or more instructions of the wave between
+// the write and this read; each such call site says why) or _salu (the mask was produced by the scalar unit, which needs no
+// wait: the compiler itself issues v_cndmask right behind s_or_b64).  A nop delays only its own wave, about four cycles; other
+// resident waves issue meanwhile, but not for free (all of them removed, unsafely: +2.2 % on the whole prover).
+// Scalar ALU instructions do not belong in these asm strings: they write SCC, which the compiler tracks only for its own code.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned long long sg;
 GL_D u64 mad_co(u32 a, u32 b, u64 c, sg& k) {  // a * b + c, carry-out in k
