@@ -250,28 +250,49 @@ GL_HD void mds_full(u64* s, const unsigned long long* rc) {
         l[i] = (u32)s[i];
         h[i] = (u32)(s[i] >> 32);
     }
-#define P2_MDS_TERM(i, K)                          \
-    al = gl::madk<K>(l[((i) + r) % 12], al);       \
-    ah = gl::madk<K>(h[((i) + r) % 12], ah);
+    // One asm block per output word: 24 (26) mads on two accumulators.  As separate statements each mad is followed by the
+    // compiler's boundary pad (it defines an SGPR pair, the unused carry-out, and the compiler cannot see that nobody reads
+    // it): 2 500 s_nop per permutation.  29 operands -- the limit is 30.
+#define P2_MDS_T(n, K) "v_mad_u64_u32 %[al], %[d], %[l" #n "], " #K ", %[al]\n\tv_mad_u64_u32 %[ah], %[d], %[h" #n "], " #K ", %[ah]\n\t"
+#define P2_MDS_TAIL P2_MDS_T(1, 15) P2_MDS_T(2, 41) P2_MDS_T(3, 16) P2_MDS_T(4, 2) P2_MDS_T(5, 28) P2_MDS_T(6, 13) P2_MDS_T(7, 13) \
+                    P2_MDS_T(8, 39) P2_MDS_T(9, 18) P2_MDS_T(10, 34) P2_MDS_T(11, 20)
+#define P2_MDS_IN(r)                                                                                                                          \
+    [l0] "v"(l[(0 + r) % 12]), [h0] "v"(h[(0 + r) % 12]), [l1] "v"(l[(1 + r) % 12]), [h1] "v"(h[(1 + r) % 12]), [l2] "v"(l[(2 + r) % 12]),     \
+        [h2] "v"(h[(2 + r) % 12]), [l3] "v"(l[(3 + r) % 12]), [h3] "v"(h[(3 + r) % 12]), [l4] "v"(l[(4 + r) % 12]), [h4] "v"(h[(4 + r) % 12]), \
+        [l5] "v"(l[(5 + r) % 12]), [h5] "v"(h[(5 + r) % 12]), [l6] "v"(l[(6 + r) % 12]), [h6] "v"(h[(6 + r) % 12]), [l7] "v"(l[(7 + r) % 12]), \
+        [h7] "v"(h[(7 + r) % 12]), [l8] "v"(l[(8 + r) % 12]), [h8] "v"(h[(8 + r) % 12]), [l9] "v"(l[(9 + r) % 12]), [h9] "v"(h[(9 + r) % 12]), \
+        [l10] "v"(l[(10 + r) % 12]), [h10] "v"(h[(10 + r) % 12]), [l11] "v"(l[(11 + r) % 12]), [h11] "v"(h[(11 + r) % 12])
 #pragma unroll
     for (int r = 0; r < 12; r++) {
         u64 al, ah;
+        gl::sg dead;
         if (rc) {
-            al = gl::madk_s<17>(l[r], (u64)(u32)rc[r]);
-            ah = gl::madk_s<17>(h[r], (u64)(rc[r] >> 32));
+            const u64 rl = (u64)(u32)rc[r], rh = (u64)(rc[r] >> 32);
+            if (r == 0)
+                asm("v_mad_u64_u32 %[al], %[d], %[l0], 17, %[rl]\n\tv_mad_u64_u32 %[ah], %[d], %[h0], 17, %[rh]\n\t" P2_MDS_TAIL
+                    "v_mad_u64_u32 %[al], %[d], %[l0], 8, %[al]\n\tv_mad_u64_u32 %[ah], %[d], %[h0], 8, %[ah]"
+                    : [al] "=&v"(al), [ah] "=&v"(ah), [d] "=&s"(dead)
+                    : [rl] "s"(rl), [rh] "s"(rh), P2_MDS_IN(r));
+            else
+                asm("v_mad_u64_u32 %[al], %[d], %[l0], 17, %[rl]\n\tv_mad_u64_u32 %[ah], %[d], %[h0], 17, %[rh]\n\t" P2_MDS_TAIL
+                    : [al] "=&v"(al), [ah] "=&v"(ah), [d] "=&s"(dead)
+                    : [rl] "s"(rl), [rh] "s"(rh), P2_MDS_IN(r));
         } else {
-            al = gl::madk0<17>(l[r]);
-            ah = gl::madk0<17>(h[r]);
-        }
-        P2_MDS_TERM(1, 15) P2_MDS_TERM(2, 41) P2_MDS_TERM(3, 16) P2_MDS_TERM(4, 2) P2_MDS_TERM(5, 28) P2_MDS_TERM(6, 13)
-        P2_MDS_TERM(7, 13) P2_MDS_TERM(8, 39) P2_MDS_TERM(9, 18) P2_MDS_TERM(10, 34) P2_MDS_TERM(11, 20)
-        if (r == 0) {
-            al = gl::madk<8>(l[0], al);
-            ah = gl::madk<8>(h[0], ah);
+            if (r == 0)
+                asm("v_mad_u64_u32 %[al], %[d], %[l0], 17, 0\n\tv_mad_u64_u32 %[ah], %[d], %[h0], 17, 0\n\t" P2_MDS_TAIL
+                    "v_mad_u64_u32 %[al], %[d], %[l0], 8, %[al]\n\tv_mad_u64_u32 %[ah], %[d], %[h0], 8, %[ah]"
+                    : [al] "=&v"(al), [ah] "=&v"(ah), [d] "=&s"(dead)
+                    : P2_MDS_IN(r));
+            else
+                asm("v_mad_u64_u32 %[al], %[d], %[l0], 17, 0\n\tv_mad_u64_u32 %[ah], %[d], %[h0], 17, 0\n\t" P2_MDS_TAIL
+                    : [al] "=&v"(al), [ah] "=&v"(ah), [d] "=&s"(dead)
+                    : P2_MDS_IN(r));
         }
         res[r] = fold_al_ah(al, ah);
     }
-#undef P2_MDS_TERM
+#undef P2_MDS_T
+#undef P2_MDS_TAIL
+#undef P2_MDS_IN
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = res[i];
     return;
