@@ -282,12 +282,19 @@ __device__ __forceinline__ void wave_lds_sync() {
 // that two workgroups share a compute unit and the load / store phases of one overlap the butterflies of the other.  (One
 // 139 KiB workgroup per compute unit leaves the SIMDs idle while its waves wait on memory: a wave's own prefetch cannot
 // help, vmcnt retires in order.)  Natural-order input and bit-reversed output only (the LDE), which is where the time is.
+// block id -> work id such that the work ids handled by one XCD (block ids congruent mod 8) are consecutive
+__device__ __forceinline__ u32 xcd_swizzle(u32 b, u32 grid) { return (grid & 7) ? b : (b & 7) * (grid >> 3) + (b >> 3); }
 template <bool SPLIT>
 __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
     extern __shared__ __align__(16) u64 lds[];
     const int logn = SPLIT ? a.logn - 1 : a.logn;  // size of the transform this workgroup runs in LDS
     const u32 n = 1u << logn, T = n >> 4, t = threadIdx.x;
-    const u32 unit = SPLIT ? blockIdx.x >> 1 : blockIdx.x, half = SPLIT ? (blockIdx.x & 1) : 0;
+    // XCD placement: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an L2), and the 8 cosets (x 2
+    // halves) of one column all read the SAME coefficient column.  Left in launch order they land on all eight L2s and the
+    // column is fetched eight times (round 2, PMC: read = written, where the algorithm reads 1/8 of what it writes); with
+    // the ids of one XCD renumbered consecutively a column's workgroups share one L2 and the column is fetched once.
+    const u32 bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const u32 unit = SPLIT ? bid >> 1 : bid, half = SPLIT ? (bid & 1) : 0;
     const u32 col = unit / a.cosets, coset = unit % a.cosets;
     const u32 blk = a.block_of_coset[coset];
     const size_t full = (size_t)1 << a.logn;
