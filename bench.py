@@ -118,10 +118,19 @@ def main():
     ap.add_argument("--workload", choices=["aes-gcm", "elgamal"], default="aes-gcm",
                     help="aes-gcm = BASELINE.json's metric workload (default); elgamal = configs[3]'s circuit")
     ap.add_argument("--pcie-steps", type=int, default=2, help="extra untimed-for-`value` steps through the host path (value_pcie_inclusive); 0 = skip")
+    ap.add_argument("--config", type=int, choices=[3, 4, 5], default=None,
+                    help="BASELINE.json configs[i-1] as one flag: 3 = AES-GCM 1 KiB (the default workload), 4 = ElGamal with the per-GPU share of "
+                         "batch 1024 over 8 GPUs (--workload elgamal --batch 128), 5 = AES-GCM 64 KiB with the per-GPU share of batch 256 over "
+                         "8 GPUs (--plaintext-bytes 65536 --batch 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=32, help="OpenMP threads of the cpu_baseline leg (32 is the measured optimum of the port on the GPU boxes' hosts)")
     ap.add_argument("--cpu-sample", type=int, default=3, help="proofs timed on the host for cpu_baseline (median, after one warm-up)")
     args = ap.parse_args()
+
+    if args.config == 4:
+        args.workload, args.batch = "elgamal", 128
+    elif args.config == 5:
+        args.plaintext_bytes, args.batch = 65536, 32
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD torch.distributed.run (never an
     # exec -- and before anything in this process touches the GPU), relay rank 0's JSON line and leave with the child's code.

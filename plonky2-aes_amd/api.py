@@ -483,6 +483,14 @@ class CircuitData:
             raise P2Error(_err())
         return list(out[: n.value])
 
+    def debug_read_bytes(self, name, index=0, cap=1 << 26):
+        """The same buffer as little-endian u64 bytes (10^8-word buffers of the 2^19-row circuits: hash, do not list)."""
+        out = (u64 * cap)()
+        n = sz()
+        if lib().p2_circuit_debug_read(self.gpu(), name.encode(), index, out, cap, C.byref(n)):
+            raise P2Error(_err())
+        return bytes(memoryview(out).cast("B")[: 8 * n.value])
+
 
 class AesGcmTarget:
     """AesGcmTarget<NK, 4, NR, L, TAG> (aes-gcm/src/circuit_gcm.rs:24-209)."""

@@ -593,8 +593,9 @@ __global__ void k_quotient_chunks_rev(const u64* __restrict__ r, u64* __restrict
 
 // ------------------------------------------------------------------------------------------- witness
 struct WitnessArgs {
-    const p2::Op* ops;
-    const u32* level_offsets;
+    const p2::Op* ops;            // scheduled order (witness_schedule.h)
+    const u32* macro_offsets;     // macro m = ops[macro_offsets[m], macro_offsets[m + 1])
+    const u32* level_offsets;     // level l = macros [level_offsets[l], level_offsets[l + 1])
     u32 num_levels, num_slots, n_inputs;
     const u32* input_slots;   // [n_inputs] (shared by the batch)
     const u64* input_values;  // [batch][n_inputs]
@@ -608,11 +609,6 @@ struct WitnessArgs {
     u32 n, num_poseidon_rows;
 };
 
-// Ops a thread keeps in flight together.  On the 2^19-row AES-CTR circuit 1, 2 and 4 measure the same: its 16.5 k levels
-// are the carry chain of inc32 (a handful of ops each), so a level costs its dependent memory round trips, about 4 us,
-// whatever the width.  (It cost 15 us while every level also held a Fermat inversion -- see the levelisation in
-// builder.h, which now runs the inverse hints side by side at the end.)
-static const int WITNESS_MLP = 1;
 // PoseidonGenerator: one thread computes the whole row (these ops form sequential sponge chains).  0 ok, 1 conflict, 2 missing input
 __device__ __noinline__ int witness_poseidon_op(const WitnessArgs& a, u64* val, u32 proof, const p2::Op& o) {
     u64 w[135];
@@ -640,8 +636,49 @@ __device__ __noinline__ int witness_poseidon_op(const WitnessArgs& a, u64* val, 
     return bad;
 }
 
-// One workgroup generates one witness: ops are pre-sorted into dependency levels; every level is a parallel
-// sweep of the workgroup with a barrier in between (the op descriptors are shared by all proofs, L2-resident).
+// One op of the witness program: every operand together with the present value of the output slot (it does not depend on
+// the operands), then the table entry of a lookup (ONE load: value -> entry index and output), then the result.
+// Returns 0 ok, 1 conflict / lookup miss, 2 missing input.
+template <bool HAS_POSEIDON>
+__device__ __forceinline__ int witness_exec_op(const WitnessArgs& a, u64* val, u32* mult, u32 proof, const p2::Op& o) {
+    const u32 kind = o.kind;
+    if (kind == p2::OP_POSEIDON) return HAS_POSEIDON ? witness_poseidon_op(a, val, proof, o) : 0;
+    u64 x = 0, y = 0, z = 0;
+    const u64 cur = val[o.out];
+    if (kind != p2::OP_CONST) x = val[o.a];
+    if (kind == p2::OP_ARITH || kind == p2::OP_EQ || kind == p2::OP_EQINV) y = val[o.b];
+    if (kind == p2::OP_ARITH) z = val[o.c];
+    u64 r = 0;
+    if (kind == p2::OP_ARITH) {
+        if (x == UNSET || y == UNSET || z == UNSET) return 2;
+        r = gl::add(gl::mul(gl::mul(x, y), o.k0), gl::mul(z, o.k1));
+    } else if (kind == p2::OP_CONST) {
+        r = o.k0;
+    } else if (kind == p2::OP_LOOKUP) {
+        if (x == UNSET) return 2;
+        if (x >= 65536) return 1;                                          // not a 16-bit value
+        const u64 ent = a.lut_ent[(size_t)o.aux * 65536 + x];              // (flat entry index << 16) | output, or ~0
+        if (ent == ~0ull) return 1;                                        // not in the table
+        r = ent & 0xFFFF;
+        atomicAdd(&mult[ent >> 16], 1u);
+    } else {
+        if (x == UNSET || y == UNSET) return 2;
+        if (kind == p2::OP_EQ)
+            r = x == y ? 1 : 0;
+        else
+            r = x == y ? 0 : gl::inv(gl::sub(x, y));
+    }
+    if (cur == UNSET)
+        val[o.out] = r;
+    else if (cur != r)
+        return 1;
+    return 0;
+}
+
+// One workgroup generates one witness.  The program is scheduled (witness_schedule.h) into levels of MACROS: a macro is a short
+// straight-line run of ops that one thread executes in order (a later op of the run may read what an earlier one wrote: same
+// thread, program order), the macros of a level are independent, and a workgroup barrier separates the levels.  The
+// descriptors are shared by all proofs (L2-resident).
 template <bool HAS_POSEIDON>
 __global__ __launch_bounds__(1024) void k_witness(WitnessArgs a) {
     __shared__ int s_status;
@@ -669,100 +706,41 @@ __global__ __launch_bounds__(1024) void k_witness(WitnessArgs a) {
         if (bad) atomicMax(&s_status, 3);
     }
     __syncthreads();
-    // The op descriptors do not depend on witness values, so each thread fetches its first descriptor of level lv+1
-    // before it starts on level lv: on deep circuits (10^4 levels, descriptors streaming from HBM) the descriptor
-    // latency is the longest link of the per-level dependency chain.
+    // Neither the macro bounds nor the op descriptors depend on witness values, so each thread fetches the bounds and the first
+    // descriptor of its first macro of level lv + 1 before it starts on level lv: on deep circuits (10^3..10^4 levels,
+    // descriptors streaming from HBM) that latency is otherwise the longest link of the per-level dependency chain.
     p2::Op nxt;
-    bool have_nxt = false;
+    u32 nxt_ob = 0, nxt_oe = 0;
     u32 nbeg = a.level_offsets[0], nend = a.num_levels ? a.level_offsets[1] : nbeg;
     if (nbeg + threadIdx.x < nend) {
-        nxt = a.ops[nbeg + threadIdx.x];
-        have_nxt = true;
+        nxt_ob = a.macro_offsets[nbeg + threadIdx.x];
+        nxt_oe = a.macro_offsets[nbeg + threadIdx.x + 1];
+        nxt = a.ops[nxt_ob];
     }
     for (u32 lv = 0; lv < a.num_levels; lv++) {
         const u32 beg = nbeg, end = nend;
         const p2::Op first = nxt;
-        const bool have_first = have_nxt;
-        have_nxt = false;
+        const u32 first_ob = nxt_ob, first_oe = nxt_oe;
         if (lv + 1 < a.num_levels) {
             nbeg = end;
             nend = a.level_offsets[lv + 2];
             if (nbeg + threadIdx.x < nend) {
-                nxt = a.ops[nbeg + threadIdx.x];
-                have_nxt = true;
+                nxt_ob = a.macro_offsets[nbeg + threadIdx.x];
+                nxt_oe = a.macro_offsets[nbeg + threadIdx.x + 1];
+                nxt = a.ops[nxt_ob];
             }
         }
-        // stages of an op: descriptor, then every operand together with the present value of the output slot (it does
-        // not depend on the operands), then the table entry of a lookup; WITNESS_MLP ops go through them side by side
-        for (u32 k0 = beg + threadIdx.x; k0 < end; k0 += WITNESS_MLP * blockDim.x) {
-            p2::Op o[WITNESS_MLP];
-            bool act[WITNESS_MLP];
-#pragma unroll
-            for (int u = 0; u < WITNESS_MLP; u++) {
-                const u32 k = k0 + u * blockDim.x;
-                act[u] = k < end;
-                if (act[u]) o[u] = (u == 0 && have_first && k0 == beg + threadIdx.x) ? first : a.ops[k];
-            }
-            u64 x[WITNESS_MLP], y[WITNESS_MLP], z[WITNESS_MLP], cur[WITNESS_MLP], ent[WITNESS_MLP];
-#pragma unroll
-            for (int u = 0; u < WITNESS_MLP; u++) {
-                x[u] = y[u] = z[u] = cur[u] = 0;
-                if (!act[u] || o[u].kind == p2::OP_POSEIDON) continue;
-                const u32 kind = o[u].kind;
-                cur[u] = val[o[u].out];
-                if (kind != p2::OP_CONST) x[u] = val[o[u].a];
-                if (kind == p2::OP_ARITH || kind == p2::OP_EQ || kind == p2::OP_EQINV) y[u] = val[o[u].b];
-                if (kind == p2::OP_ARITH) z[u] = val[o[u].c];
-            }
-#pragma unroll
-            for (int u = 0; u < WITNESS_MLP; u++) {
-                ent[u] = ~0ull;  // (flat entry index << 16) | output, or ~0
-                if (act[u] && o[u].kind == p2::OP_LOOKUP && x[u] < 65536) ent[u] = a.lut_ent[(size_t)o[u].aux * 65536 + x[u]];
-            }
-#pragma unroll
-            for (int u = 0; u < WITNESS_MLP; u++) {
-                if (!act[u]) continue;
-                const u32 kind = o[u].kind;
-                u64 r = 0;
-                int bad = 0;
-                if (kind == p2::OP_POSEIDON) {
-                    if (HAS_POSEIDON) bad = witness_poseidon_op(a, val, proof, o[u]);
-                    if (bad) atomicMax(&s_status, bad == 1 ? 3 : 2);
-                    continue;
-                }
-                if (kind == p2::OP_ARITH) {
-                    if (x[u] == UNSET || y[u] == UNSET || z[u] == UNSET)
-                        bad = 2;
-                    else
-                        r = gl::add(gl::mul(gl::mul(x[u], y[u]), o[u].k0), gl::mul(z[u], o[u].k1));
-                } else if (kind == p2::OP_CONST) {
-                    r = o[u].k0;
-                } else if (kind == p2::OP_LOOKUP) {
-                    if (x[u] == UNSET) {
-                        bad = 2;
-                    } else if (ent[u] == ~0ull) {  // not a 16-bit value, or not in the table
-                        bad = 1;
-                    } else {
-                        r = ent[u] & 0xFFFF;
-                        atomicAdd(&mult[ent[u] >> 16], 1u);
-                    }
-                } else {
-                    if (x[u] == UNSET || y[u] == UNSET)
-                        bad = 2;
-                    else if (kind == p2::OP_EQ)
-                        r = x[u] == y[u] ? 1 : 0;
-                    else
-                        r = x[u] == y[u] ? 0 : gl::inv(gl::sub(x[u], y[u]));
-                }
-                if (!bad) {
-                    if (cur[u] == UNSET)
-                        val[o[u].out] = r;
-                    else if (cur[u] != r)
-                        bad = 1;
-                }
-                if (bad) atomicMax(&s_status, bad == 1 ? 3 : 2);  // conflict (1) outranks missing input (2); remapped below
+        int worst = 0;
+        for (u32 m = beg + threadIdx.x; m < end; m += blockDim.x) {
+            const bool pre = m == beg + threadIdx.x;
+            const u32 ob = pre ? first_ob : a.macro_offsets[m], oe = pre ? first_oe : a.macro_offsets[m + 1];
+            for (u32 k = ob; k < oe; k++) {
+                const p2::Op o = (pre && k == ob) ? first : a.ops[k];
+                const int bad = witness_exec_op<HAS_POSEIDON>(a, val, mult, proof, o);
+                if (bad) worst = max(worst, bad == 1 ? 3 : 2);  // conflict (1) outranks missing input (2); remapped below
             }
         }
+        if (worst) atomicMax(&s_status, worst);
         __syncthreads();
     }
     if (threadIdx.x == 0) a.status[proof] = s_status == 3 ? 1 : s_status;

@@ -13,6 +13,7 @@
 
 #include "capi_common.h"
 #include "os_random.h"
+#include "witness_schedule.h"
 #include "kernels.h"
 #include "kernels2.h"
 
@@ -71,7 +72,8 @@ struct p2_circuit {
     std::vector<u32> arities;
     // ---- static device data
     Op* d_ops = nullptr;
-    u32* d_level_offsets = nullptr;
+    u32 *d_level_offsets = nullptr, *d_macro_offsets = nullptr;
+    u32 witness_levels = 0, witness_macros = 0;
     int32_t* d_wire_slot = nullptr;
     u64* d_lut_ent = nullptr;
     u32 *d_lut_pairs = nullptr, *d_lut_offsets = nullptr, *d_num_lookups = nullptr;
@@ -111,6 +113,7 @@ struct p2_circuit {
     // tuning options (p2_circuit_set_option; the environment is read ONCE, at load): proofs per chunk, proving streams,
     // phase timing of the host path on stderr
     size_t opt_chunk = 128, opt_streams = 2;
+    u32 opt_witness_fuse = 8;  // most ops per witness macro (P2AES_WITNESS_FUSE at load; 1 = one op per thread per level)
     bool opt_debug_timing = false;
     // host-path staging (p2_prove_batch): persistent device buffers + pinned host buffers, one set per concurrent caller
     std::vector<struct Staging*> staging_free;
@@ -310,8 +313,15 @@ static int circuit_setup(p2_circuit* C) {
     const u32 R = c.cfg.num_routed_wires, ncc = c.num_constants_cols(), np = c.num_preprocessed();
     if (c.cfg.num_challenges > 2) return set_error("k_perm_chunks handles at most two challenges"), P2_ERR_INVALID;
     if (c.num_partial_products() + 1 > PERM_MAX_CHUNKS) return set_error("more partial-product chunks than k_perm_scan holds in registers"), P2_ERR_INVALID;
-    if (upload(C, &C->d_ops, c.ops.data(), c.ops.size())) return P2_ERR_HIP;
-    if (upload(C, &C->d_level_offsets, c.level_offsets.data(), c.level_offsets.size())) return P2_ERR_HIP;
+    {
+        // the witness program, rescheduled for the device: levels of macros (witness_schedule.h)
+        WitnessSchedule ws = schedule_witness(c, C->opt_witness_fuse);
+        C->witness_levels = (u32)ws.level_offsets.size() - 1;
+        C->witness_macros = (u32)ws.macro_offsets.size() - 1;
+        if (upload(C, &C->d_ops, ws.ops.data(), ws.ops.size())) return P2_ERR_HIP;
+        if (upload(C, &C->d_macro_offsets, ws.macro_offsets.data(), ws.macro_offsets.size())) return P2_ERR_HIP;
+        if (upload(C, &C->d_level_offsets, ws.level_offsets.data(), ws.level_offsets.size())) return P2_ERR_HIP;
+    }
     if (upload(C, &C->d_wire_slot, c.wire_slot.data(), c.wire_slot.size())) return P2_ERR_HIP;
     {
         // witness generation resolves a lookup with ONE load: input value -> (flat entry index << 16) | output
@@ -626,8 +636,9 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
     {
         WitnessArgs a{};
         a.ops = C->d_ops;
+        a.macro_offsets = C->d_macro_offsets;
         a.level_offsets = C->d_level_offsets;
-        a.num_levels = (u32)c.level_offsets.size() - 1;
+        a.num_levels = C->witness_levels;
         a.num_slots = c.num_slots;
         a.n_inputs = n_inputs;
         a.input_slots = C->cur->d_input_slots;
@@ -1045,6 +1056,7 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
         // environment defaults for the options, read once here (never per call)
         if (const char* e = getenv("P2AES_CHUNK")) C->opt_chunk = (size_t)std::max(1, atoi(e));
         if (const char* e = getenv("P2AES_STREAMS")) C->opt_streams = (size_t)std::min(8, std::max(1, atoi(e)));
+        if (const char* e = getenv("P2AES_WITNESS_FUSE")) C->opt_witness_fuse = (u32)std::min(1024, std::max(1, atoi(e)));
         C->opt_debug_timing = getenv("P2AES_DEBUG_TIMING") != nullptr;
         if (const char* e = getenv("P2AES_TEST_FAIL_ALLOC_AFTER")) C->fail_alloc_after = atol(e);
         C->pbytes = proof_bytes(c);

@@ -127,6 +127,21 @@ class OracleCircuit:
         lib().orc_trace_get(self.h, name.encode(), out, n)
         return list(out)
 
+    def trace_bytes(self, name):
+        """The same buffer as little-endian u64 bytes (for hashing 10^8-word buffers without building Python ints)."""
+        n = lib().orc_trace_len(self.h, name.encode())
+        out = (C.c_uint64 * max(n, 1))()
+        lib().orc_trace_get(self.h, name.encode(), out, n)
+        return bytes(memoryview(out).cast("B")[: 8 * n])
+
+    def generate_witness_bytes(self, pw_map, cap):
+        """(status, wires [num_wires][n] column-major as little-endian u64 bytes)."""
+        ts = (C.c_uint64 * len(pw_map))(*pw_map.keys())
+        vs = (C.c_uint64 * len(pw_map))(*pw_map.values())
+        out = (C.c_uint64 * cap)()
+        st = lib().orc_generate_witness(self.h, ts, vs, len(pw_map), out)
+        return st, (bytes(memoryview(out).cast("B")) if st == 0 else None)
+
 
 def gcm_encrypt(key, iv, pt):
     ct, tag = C.create_string_buffer(max(len(pt), 1)), C.create_string_buffer(16)

@@ -279,10 +279,12 @@ def test_full_size_aes_gcm_1kib_batch(gpu, orc):
     assert status2 == [0, 1, 0] and proofs2[0] == proofs[0] and proofs2[2] == proofs[2]
 
 
-def test_64kib_deep_circuit_2_19_rows(gpu):
+def test_64kib_deep_circuit_2_19_rows(gpu, orc):
     """BASELINE.json configs[4] shape: AesGcm128Target<65536> (n = 2^19 rows, 10.7 M witness ops, 951 MB blob).
-    The oracle needs minutes per proof here, so the checks are size-independent properties: the independent verifier
-    accepts, proving is deterministic, distinct witnesses give distinct proofs, a wrong ciphertext byte is an error."""
+    The oracle needs minutes per proof here (its byte-exact proof is frozen in tests/golden/proof_digests.json and held against
+    the GPU in test_full_size_workloads_match_the_frozen_digests); on random inputs the checks are the wire matrices against
+    the oracle's witness generation and size-independent properties: the independent verifier accepts, proving is
+    deterministic, distinct witnesses give distinct proofs, a wrong ciphertext byte is an error."""
     r = random.Random(5)
     L = 65536
     keys = [(bytes(r.randrange(256) for _ in range(16)), bytes(r.randrange(256) for _ in range(12)), bytes(r.randrange(256) for _ in range(L)))
@@ -291,6 +293,16 @@ def test_64kib_deep_circuit_2_19_rows(gpu):
     assert data.info["degree_bits"] == 19 and data.info["num_fri_rounds"] == 4
     proofs, status = data.prove_batch(pws)
     assert status == [0, 0, 0]
+    # witness generation IS within the oracle's reach at this size (seconds): every wire matrix of the batch, cell for cell
+    oc = orc.OracleCircuit(data.blob)
+    n, W = 1 << 19, data.info["num_wires"]
+    for i, pw in enumerate(pws):
+        ost, wires = oc.generate_witness_bytes(pw.map, W * n)
+        assert ost == 0
+        got = data.debug_read_bytes("wires", i, cap=W * n)
+        assert len(got) == 8 * 80 * n and got == wires[:len(got)], "witness %d: GPU wire matrix differs from the oracle's" % i
+        assert not any(wires[len(got):])            # the columns the device does not materialise are zero
+        del wires, got
     vd = data.verifier_data()
     for p in proofs[:2]:
         data.verify(p, vd)
@@ -549,6 +561,28 @@ def test_same_blob_on_every_visible_device(gpu):
         gpu.CircuitData.prove_batch_multi([handles[0], other], mixed)
 
 
+def test_bench_two_ranks_hip_prover(gpu):
+    """The N > 1 path of bench.py with the HIP prover, not the oracle: `bench.py --gpus 2` starts two ranks itself (a child
+    torch.distributed.run; this test starts bench.py as a CHILD process as well, nothing is exec'ed from a process that holds the
+    GPU).  On a one-GPU box both ranks share device 0 (P2AES_BENCH_REHEARSAL=1: gloo for the barrier and the MAX over ranks,
+    since RCCL refuses two ranks on one device); the sharding, the per-rank proving, the timing protocol and the JSON line
+    are the ones the driver's 8-GPU run uses."""
+    import subprocess
+    import sys
+    env = dict(os.environ, P2AES_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--pcie-steps", "0",
+                        "--plaintext-bytes", "64", "--batch", "8"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]           # rank 0 prints ONE JSON line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and len(out["devices"]) == 2
+    assert out["value"] > 0 and out["scaling"] == "weak" and out["unit"] == "proofs/s"
+    assert out["config"]["proofs_per_step_per_gpu"] == 8
+    assert abs(out["value"] - 2 * 8 * out["steps"] / (out["ms_per_step"] * out["steps"] * 1e-3)) <= 0.01 * out["value"]   # whole-job aggregate
+
+
 def test_zk_full_width_key_and_os_key(gpu, orc):
     """The blinding PRF takes a 256-bit key: every key word matters, the oracle reproduces proofs under a full key, and
     two handles with the default (OS-drawn) key blind differently."""
@@ -590,6 +624,30 @@ def test_gpu_proofs_match_the_frozen_digests(gpu):
         proof = data.prove(pws[0])
         assert len(proof) == want["proof_bytes"] and hashlib.sha256(proof).hexdigest() == want["proof_sha256"], name
         data.verify(proof)
+
+
+@pytest.mark.parametrize("name", ["aes_gcm_128_1024", "elgamal_encrypt", "aes_gcm_128_65536"])
+def test_full_size_workloads_match_the_frozen_digests(gpu, name):
+    """BASELINE.json's three GPU workloads at FULL size against digests the oracle wrote once in the build container
+    (tests/golden/proof_digests.json "large_cases", tools/make_proof_digests.py --large; the n = 2^19 proof took the oracle
+    minutes on 8 cores, see oracle_wall_seconds): compiled circuit, verifier data, every intermediate stage in pipeline order
+    (wire matrix, caps, challenges, Z / partial products / lookup polynomials, quotient chunks, FRI input, PoW witness, query
+    indices) and the serialised proof, byte for byte, with no oracle in the loop.  The witness sits in slot 1 of a two-proof
+    batch, so the batch stride of every buffer is exercised as well."""
+    import digest_cases as D
+    want = D.fixture()["large_cases"][name]
+    data, pws = D.large_case(gpu, name)
+    assert data.info["degree_bits"] == want["degree_bits"]
+    assert hashlib.sha256(data.blob).hexdigest() == want["blob_sha256"]
+    assert D.sha_words(data.verifier_data()) == want["verifier_data_sha256"]
+    proofs, status = data.prove_batch([pws[0], pws[0]])
+    assert status == [0, 0]
+    got = D.stage_digests_gpu(data, 1)
+    for stage in D.STAGE_ORDER:
+        assert got[stage] == want["stages"][stage], "stage %s differs from the frozen oracle digest (first divergence in pipeline order)" % stage
+    for p in proofs:
+        assert len(p) == want["proof_bytes"] and hashlib.sha256(p).hexdigest() == want["proof_sha256"]
+    data.verify(proofs[1])
 
 
 def test_pow_phases_find_the_smallest_witness(gpu, orc):

@@ -634,3 +634,25 @@ def test_proof_digests_are_frozen(pkg, orc):
         assert got == gold["cases"][name], name
         seen += 1
     assert seen == len(gold["cases"]) == 7
+
+
+@pytest.mark.parametrize("name", ["aes_gcm_128_1024", "elgamal_encrypt"])
+def test_full_size_workload_digests_are_frozen(pkg, orc, name):
+    """Round 3: the same for BASELINE.json's GPU workloads at full size (the bench circuit AesGcm128Target<1024> and the ElGamal
+    encryption circuit), including a digest of every intermediate stage of the oracle's proof.  The third large entry,
+    AesGcm128Target<65536> (n = 2^19 rows), costs the oracle tens of minutes per proof: it was written once by
+    tools/make_proof_digests.py --large in the build container and is held against the GPU prover only
+    (test_gpu_parity.py::test_full_size_workloads_match_the_frozen_digests)."""
+    import digest_cases as D
+    want = D.fixture()["large_cases"][name]
+    data, pws = D.large_case(pkg, name)
+    assert hashlib.sha256(data.blob).hexdigest() == want["blob_sha256"]
+    oc = orc.OracleCircuit(data.blob)
+    st, proof = oc.prove(pws[0].map, trace=True)
+    assert st == 0
+    assert D.sha_words(oc.verifier_data()) == want["verifier_data_sha256"]
+    got = D.stage_digests_oracle(oc, data.info, want["live_wire_columns"] << data.info["degree_bits"])
+    for stage in D.STAGE_ORDER:
+        assert got[stage] == want["stages"][stage], stage
+    assert len(proof) == want["proof_bytes"] and hashlib.sha256(proof).hexdigest() == want["proof_sha256"]
+    assert set(D.fixture()["large_cases"]) == set(D.LARGE)
