@@ -195,6 +195,11 @@ typedef struct {
     uint32_t zero_knowledge, num_gate_kinds; /* standard_recursion_zk_config(); distinct gate types in the circuit */
 } p2_circuit_info;
 int p2_blob_info(const uint8_t* blob, size_t len, p2_circuit_info* out);
+/* The device-side schedule of a compiled circuit's witness program for macro size `fuse` (csrc/witness_schedule.h; the prover
+ * builds it at p2_circuit_load with P2AES_WITNESS_FUSE, default 8), computed AND checked on the host, no device needed:
+ * every op is kept, every slot keeps its first producer, and every operand of every op is produced in an earlier level
+ * or earlier in the op's own macro.  out = {levels, macros, largest macro, ops}.  P2_ERR_INVALID if a check fails. */
+int p2_witness_schedule_check(const uint8_t* blob, size_t len, uint32_t fuse, uint32_t out[4]);
 /* verifier_data = constants_sigmas_cap (16 digests) || circuit_digest, 68 u64 -- from p2_circuit_verifier_data */
 int p2_verify(const uint8_t* blob, size_t blob_len, const uint64_t* verifier_data, size_t verifier_data_len,
               const uint8_t* proof, size_t proof_len);

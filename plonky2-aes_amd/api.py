@@ -130,6 +130,7 @@ def lib():
         "p2_native_gctr": (None, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, sz, C.c_char_p]),
         "p2_native_aes_gcm_encrypt": (None, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, sz, C.c_char_p, C.c_char_p]),
         "p2_blob_info": (C.c_int, [C.c_char_p, sz, C.POINTER(_Info)]),
+        "p2_witness_schedule_check": (C.c_int, [C.c_char_p, sz, C.c_uint32, u32p]),
         "p2_verify": (C.c_int, [C.c_char_p, sz, u64p, sz, C.c_char_p, sz]),
         "p2_circuit_load": (vp, [C.c_char_p, sz, C.c_int]), "p2_circuit_free": (None, [vp]),
         "p2_circuit_verifier_data": (C.c_int, [vp, u64p, sz, C.POINTER(sz)]),
@@ -392,6 +393,14 @@ class CircuitData:
 
     @property
     def proof_bytes(self): return self.info["proof_bytes"]
+
+    def witness_schedule(self, fuse=8):
+        """Host-side check of the device's witness schedule for macro size `fuse` (csrc/witness_schedule.h):
+        {levels, macros, max_macro, ops}; raises if an operand would not be ready when its op runs."""
+        out = (C.c_uint32 * 4)()
+        if lib().p2_witness_schedule_check(self.blob, len(self.blob), fuse, out):
+            raise P2Error(_err())
+        return dict(zip(("levels", "macros", "max_macro", "ops"), out))
 
     def verifier_data(self):
         """constants_sigmas_cap || circuit_digest.  Computed on the device when the circuit is loaded (the reference's

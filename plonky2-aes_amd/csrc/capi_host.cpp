@@ -9,6 +9,7 @@
 #include "poseidon_cipher.h"
 #include "poseidon_fast.h"
 #include "verifier.h"
+#include "witness_schedule.h"
 
 using namespace p2;
 
@@ -502,6 +503,85 @@ int p2_blob_info(const uint8_t* blob, size_t len, p2_circuit_info* out) {
     try {
         Circuit c = deserialize(blob, len);
         fill_info(c, out);
+        return P2_OK;
+    } catch (std::exception& e) {
+        return set_error(e.what()), P2_ERR_INVALID;
+    }
+}
+int p2_witness_schedule_check(const uint8_t* blob, size_t len, uint32_t fuse, uint32_t out[4]) {
+    try {
+        Circuit c = deserialize(blob, len);
+        WitnessSchedule s = schedule_witness(c, fuse);
+        const size_t M = c.ops.size(), n = (size_t)1 << c.degree_bits;
+        const u32 R = c.cfg.num_routed_wires;
+        auto same = [](const Op& x, const Op& y) { return x.kind == y.kind && x.out == y.out && x.a == y.a && x.b == y.b && x.c == y.c && x.aux == y.aux && x.k0 == y.k0 && x.k1 == y.k1; };
+        auto slots_of = [&](const Op& o, u32* d, int& first_out) {
+            int nd = 0;
+            if (o.kind == OP_ARITH) d[nd++] = o.a, d[nd++] = o.b, d[nd++] = o.c;
+            else if (o.kind == OP_LOOKUP) d[nd++] = o.a;
+            else if (o.kind == OP_EQ || o.kind == OP_EQINV) d[nd++] = o.a, d[nd++] = o.b;
+            else if (o.kind == OP_POSEIDON) {
+                for (u32 k = 0; k < 12; k++) d[nd++] = (u32)c.wire_slot[(size_t)(PG_IN + k) * n + o.a];
+                d[nd++] = (u32)c.wire_slot[(size_t)PG_SWAP * n + o.a];
+            }
+            first_out = nd;
+            if (o.kind == OP_POSEIDON) {
+                for (u32 col = PG_OUT; col < R; col++)
+                    if (col != PG_SWAP) d[nd++] = (u32)c.wire_slot[(size_t)col * n + o.a];
+            } else {
+                d[nd++] = o.out;
+            }
+            return nd;
+        };
+        if (s.ops.size() != M || s.macro_offsets.empty() || s.macro_offsets.back() != M || s.level_offsets.back() + 1 != s.macro_offsets.size())
+            return set_error("witness schedule: shape"), P2_ERR_INVALID;
+        // first producer of every slot, in the builder's order and in the scheduled order
+        std::vector<int64_t> first_orig(c.num_slots, -1), first_sched(c.num_slots, -1);
+        u32 d[96];
+        int fo;
+        for (size_t i = 0; i < M; i++) {
+            int nd = slots_of(c.ops[i], d, fo);
+            for (int j = fo; j < nd; j++)
+                if (first_orig[d[j]] < 0) first_orig[d[j]] = (int64_t)i;
+        }
+        std::vector<u32> macro_of(M), level_of_macro(s.macro_offsets.size() - 1);
+        for (size_t l = 0; l + 1 < s.level_offsets.size(); l++)
+            for (u32 m = s.level_offsets[l]; m < s.level_offsets[l + 1]; m++) level_of_macro[m] = (u32)l;
+        for (size_t m = 0; m + 1 < s.macro_offsets.size(); m++) {
+            if (s.macro_offsets[m + 1] <= s.macro_offsets[m] || s.macro_offsets[m + 1] - s.macro_offsets[m] > std::max<u32>(fuse, 1))
+                return set_error("witness schedule: empty or oversized macro"), P2_ERR_INVALID;
+            for (u32 k = s.macro_offsets[m]; k < s.macro_offsets[m + 1]; k++) macro_of[k] = (u32)m;
+        }
+        for (size_t i = 0; i < M; i++) {
+            int nd = slots_of(s.ops[i], d, fo);
+            for (int j = fo; j < nd; j++)
+                if (first_sched[d[j]] < 0) first_sched[d[j]] = (int64_t)i;
+        }
+        for (u32 sl = 0; sl < c.num_slots; sl++) {
+            if ((first_orig[sl] < 0) != (first_sched[sl] < 0)) return set_error("witness schedule: a slot lost or gained a producer"), P2_ERR_INVALID;
+            if (first_orig[sl] >= 0 && !same(c.ops[first_orig[sl]], s.ops[first_sched[sl]])) return set_error("witness schedule: a slot changed its first producer"), P2_ERR_INVALID;
+        }
+        for (size_t i = 0; i < M; i++) {
+            int nd = slots_of(s.ops[i], d, fo);
+            for (int j = 0; j < nd; j++) {
+                const int64_t p = first_sched[d[j]];
+                if (p < 0 || p == (int64_t)i) continue;   // a user input, or this op is the producer
+                const bool earlier_level = level_of_macro[macro_of[p]] < level_of_macro[macro_of[i]];
+                const bool same_macro_before = macro_of[p] == macro_of[i] && p < (int64_t)i;
+                if (!earlier_level && !same_macro_before) return set_error("witness schedule: an operand is not ready when its op runs"), P2_ERR_INVALID;
+            }
+        }
+        // multiset of ops preserved: compare sorted fingerprints
+        auto fp = [](const Op& o) { return ((u64)o.kind * 0x9E3779B97F4A7C15ull) ^ ((u64)o.out << 32 | o.a) ^ (((u64)o.b << 32 | o.c) * 0xBF58476D1CE4E5B9ull) ^ (o.k0 * 3 + o.k1 * 5 + o.aux); };
+        std::vector<u64> fa(M), fb(M);
+        for (size_t i = 0; i < M; i++) fa[i] = fp(c.ops[i]), fb[i] = fp(s.ops[i]);
+        std::sort(fa.begin(), fa.end());
+        std::sort(fb.begin(), fb.end());
+        if (fa != fb) return set_error("witness schedule: ops changed"), P2_ERR_INVALID;
+        out[0] = (u32)s.level_offsets.size() - 1;
+        out[1] = (u32)s.macro_offsets.size() - 1;
+        out[2] = s.max_macro;
+        out[3] = (u32)M;
         return P2_OK;
     } catch (std::exception& e) {
         return set_error(e.what()), P2_ERR_INVALID;

@@ -111,6 +111,39 @@ __global__ __launch_bounds__(256) P2_HASH_WAVES void k_merkle_level(const u64* _
     for (int k = 0; k < 4; k++) o[k] = st[k];
 }
 
+// The TOP of a tree in one launch: workgroup w owns the subtree under cap node w (16 per proof) from the level at which that
+// subtree has at most 256 parents -- up to nine levels, 256, 128, ... 1 parents -- with a workgroup barrier between levels
+// instead of a kernel boundary.  Those levels hold 2^13 .. 2^4 hashes per proof: launched one by one (round 2) each of them
+// costs a whole permutation's latency plus a launch for next to no work (13 launches per tree, 54 per chunk; now 5 and 18).
+// dig = the tree's digest levels as merkle_build lays them out; level l's nodes start at 4 * (2^(bits+1) - 2^(bits-l+1)).
+__global__ __launch_bounds__(256) P2_HASH_WAVES void k_merkle_top(u64* __restrict__ dig, size_t batch_stride, u32 bits, u32 first_level, u32 num_levels) {
+    u64* base = dig + (size_t)blockIdx.y * batch_stride;
+    u32 P = ((1u << bits) >> (first_level + 1)) / gridDim.x;  // parents of this workgroup at its first level (<= 256)
+    for (u32 k = 0, l = first_level; k < num_levels; k++, l++, P >>= 1) {
+        if (threadIdx.x < P) {
+            const size_t off_c = 4 * (((size_t)2 << bits) - ((size_t)2 << (bits - l))), off_p = 4 * (((size_t)2 << bits) - ((size_t)2 << (bits - l - 1)));
+            const size_t idx = (size_t)blockIdx.x * P + threadIdx.x;
+            u64 st[12];
+            {
+                const u64* c = base + off_c + 8 * idx;
+#pragma unroll
+                for (int q = 0; q < 8; q++) st[q] = c[q];
+            }
+            {
+                u64 zero = 0;
+                asm("" : "+v"(zero));  // see k_merkle_level
+#pragma unroll
+                for (int q = 8; q < 12; q++) st[q] = zero;
+            }
+            glf::poseidon(st);
+            u64* o = base + off_p + 4 * idx;
+#pragma unroll
+            for (int q = 0; q < 4; q++) o[q] = st[q];
+        }
+        __syncthreads();  // the parents just written are the next level's children (same workgroup: workgroup-scope ordering is enough)
+    }
+}
+
 // standalone permutation (parity test entry point)
 __global__ void k_poseidon_states(u64* states, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -500,6 +533,7 @@ struct Pass1Args {
     u64* out;
     const u64* tw;   // w^i for i < n (forward or inverse root of order n)
     const u64* pre;  // [cosets][n] scale applied on load, or null
+    const u64* out_tw;  // k_ntt_pass1_r16: [n1][n2] w^(rev(row) j2), the output twiddle in output order
     size_t in_col_stride, out_col_stride, in_batch_stride, out_batch_stride;
     int logn, log_n1, log_T, cosets, in_coset_blocks;
     u32 block_of_coset[8];
@@ -542,6 +576,97 @@ __global__ __launch_bounds__(256) void k_ntt_pass1(Pass1Args a) {
         u32 j2 = j2_0 + t;
         out[(size_t)r * n2 + j2] = gl::mul_nb(lds[e], a.tw[(size_t)k1 * j2]);
     }
+}
+// ---- pass 1, register-blocked (round 3).  The tile of n1 rows x T columns (4096 elements) is ONE flat array e = row * T + t:
+// the n1-point DIF down the rows of every column is then exactly the first log n1 stages of a 4096-point DIF over e -- the
+// same pairs (e, e + h), h >= T -- with twiddles that depend on the ROW part of e only.  So the step structure of k_ntt_r16
+// carries over: 256 threads own 16 points each, the first log n1 mod 4 stages come straight from the (tile-strided) global
+// loads, every further four stages cost one LDS exchange, and a last trip puts the data in store order.  n = 2^19 (n1 = 128):
+// 3 + 4 stages, 2 barriers, where k_ntt_pass1 runs 7 radix-2 LDS stages with 7 barriers and gathers its output twiddle
+// w^(k1 j2) with a stride of k1 elements (64 cache lines per wave load); here that twiddle comes from a table laid out in
+// output order (Pass1Args::out_tw: [row][j2] = w^(rev(row) j2), n entries shared by every column, coset and proof).
+__device__ __forceinline__ void ntt_p1_load_tw(u64* w, const u64* __restrict__ tw, u32 tp, int m, int log_T, int tw_log, int nstages) {
+#pragma unroll
+    for (int A = 0; A < 4; A++) {
+        if (A >= nstages) break;
+        const int half = 8 >> A, base = 16 - 2 * half, q = m + 4 - A - log_T;  // root of order 2^q over the rows; q >= 1 for every stage that is run
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (j < half) w[base + j] = tw[(size_t)((tp + ((u32)j << m)) >> log_T) << (tw_log - q)];
+    }
+}
+__global__ __launch_bounds__(256, 4) void k_ntt_pass1_r16(Pass1Args a) {
+    extern __shared__ __align__(16) u64 lds[];
+    const u32 T = 1u << a.log_T, t = threadIdx.x;
+    const int log_n2 = a.logn - a.log_n1;
+    const u32 n2 = 1u << log_n2, tiles = n2 >> a.log_T;
+    const u32 bid = xcd_swizzle(blockIdx.x, gridDim.x);  // the 8 cosets of one (column, tile) read the same input: one XCD, one L2
+    const u32 tile = bid % tiles, cc = bid / tiles, col = cc / a.cosets, coset = cc % a.cosets;
+    const u32 blk = a.block_of_coset[coset];
+    const size_t n = (size_t)1 << a.logn;
+    const u64* in = a.in + (size_t)blockIdx.y * a.in_batch_stride + (size_t)col * a.in_col_stride + (a.in_coset_blocks ? (size_t)blk * n : 0);
+    u64* out = a.out + (size_t)blockIdx.y * a.out_batch_stride + (size_t)col * a.out_col_stride + (size_t)blk * n;
+    const u64* pre = a.pre ? a.pre + (size_t)coset * n : nullptr;
+    const u32 j2_0 = tile << a.log_T;
+    u64 x[16], w[15];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 e = t + 256 * k;
+        const u32 idx = (e >> a.log_T) * n2 + j2_0 + (e & (T - 1));  // < n <= 2^22
+        x[k] = in[idx];
+        if (pre) x[k] = gl::mul_nb(x[k], pre[idx]);
+    }
+    const int rem = (a.log_n1 & 3) ? (a.log_n1 & 3) : 4;
+    ntt_p1_load_tw(w, a.tw, t, 8, a.log_T, a.logn, rem);
+    ntt_r16_stage<0>(x, w);
+    if (rem >= 2) ntt_r16_stage<1>(x, w);
+    if (rem >= 3) ntt_r16_stage<2>(x, w);
+    if (rem >= 4) ntt_r16_stage<3>(x, w);
+    u32 base_idx = t, stride = 256;
+    for (int logN = 12 - rem; logN - 4 >= a.log_T; logN -= 4) {
+        const int m = logN - 4;
+        const u32 tp = t & ((1u << m) - 1);
+        ntt_p1_load_tw(w, a.tw, tp, m, a.log_T, a.logn, 4);  // in flight across the barrier
+        {
+            const NttLdsWalk wr(base_idx, stride);
+#pragma unroll
+            for (int r = 0; r < 16; r++) wr.at(lds, r) = x[r];
+        }
+        __syncthreads();
+        base_idx = ((t >> m) << logN) | tp;
+        stride = 1u << m;
+        {
+            const NttLdsWalk rd(base_idx, stride);
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = rd.at(lds, r);
+        }
+        ntt_r16_stage<0>(x, w);
+        ntt_r16_stage<1>(x, w);
+        ntt_r16_stage<2>(x, w);
+        ntt_r16_stage<3>(x, w);
+    }
+    {
+        const NttLdsWalk wr(base_idx, stride);
+#pragma unroll
+        for (int r = 0; r < 16; r++) wr.at(lds, r) = x[r];
+    }
+    __syncthreads();
+    const NttLdsWalk fin(t, 256);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 e = t + 256 * k;
+        const u32 o = (e >> a.log_T) * n2 + j2_0 + (e & (T - 1));
+        out[o] = gl::mul_nb(fin.at(lds, k), a.out_tw[o]);
+    }
+}
+// out_tw[r * n2 + j2] = tw[rev(r) * j2]   (r < n1, j2 < n2; tw = w^i, i < n)
+__global__ void k_pass1_out_tw(const u64* __restrict__ tw, u64* __restrict__ out_tw, int logn, int log_n1) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> logn) return;
+    const int log_n2 = logn - log_n1;
+    const u32 r = (u32)(i >> log_n2), j2 = (u32)(i & (((size_t)1 << log_n2) - 1));
+    const u32 k1 = log_n1 ? (__brev(r) >> (32 - log_n1)) : 0;
+    out_tw[i] = tw[(size_t)k1 * j2];
 }
 // out[i] = in[rev(i)] (* post[row][i]) on `blocks` consecutive blocks of n per column
 __global__ void k_bitrev_copy(const u64* in, size_t in_col_stride, size_t in_batch_stride, u64* out, size_t out_col_stride, size_t out_batch_stride, int logn,
@@ -636,51 +761,106 @@ __device__ __noinline__ int witness_poseidon_op(const WitnessArgs& a, u64* val, 
     return bad;
 }
 
-// One op of the witness program: every operand together with the present value of the output slot (it does not depend on
-// the operands), then the table entry of a lookup (ONE load: value -> entry index and output), then the result.
-// Returns 0 ok, 1 conflict / lookup miss, 2 missing input.
+// Most ops per macro the kernel is unrolled for (witness_schedule.h caps the schedule at this).
+static const int WITNESS_KMAX = 8;
+
+// One MACRO of the witness program: up to WITNESS_KMAX ops that one thread runs in order (witness_schedule.h).  What a level
+// costs is its chain of dependent memory round trips (a microsecond or more each: the slot array of a 2^19-row circuit is
+// 85 MB per proof, the descriptors stream from HBM), not its arithmetic, so the macro is arranged to need as few as possible:
+//   1. all descriptors of the macro (contiguous);
+//   2. every operand of every op, and the present value of every output slot, TOGETHER -- whether or not an earlier op of
+//      the macro is about to produce it;
+//   3. the ops in order, an operand that an earlier op of the macro produced taken from that op's result in registers
+//      (forwarding) instead of from memory; only a table lookup whose input is computed inside the macro adds a round trip.
+// A carry chain (inc32: add, is_equal, mul, select, select, next byte ...) thus costs two round trips per macro instead of
+// two per op.  Returns 0 ok, 2 missing input, 3 conflict / lookup miss (the encoding of s_status).
 template <bool HAS_POSEIDON>
-__device__ __forceinline__ int witness_exec_op(const WitnessArgs& a, u64* val, u32* mult, u32 proof, const p2::Op& o) {
-    const u32 kind = o.kind;
-    if (kind == p2::OP_POSEIDON) return HAS_POSEIDON ? witness_poseidon_op(a, val, proof, o) : 0;
-    u64 x = 0, y = 0, z = 0;
-    const u64 cur = val[o.out];
-    if (kind != p2::OP_CONST) x = val[o.a];
-    if (kind == p2::OP_ARITH || kind == p2::OP_EQ || kind == p2::OP_EQINV) y = val[o.b];
-    if (kind == p2::OP_ARITH) z = val[o.c];
-    u64 r = 0;
-    if (kind == p2::OP_ARITH) {
-        if (x == UNSET || y == UNSET || z == UNSET) return 2;
-        r = gl::add(gl::mul(gl::mul(x, y), o.k0), gl::mul(z, o.k1));
-    } else if (kind == p2::OP_CONST) {
-        r = o.k0;
-    } else if (kind == p2::OP_LOOKUP) {
-        if (x == UNSET) return 2;
-        if (x >= 65536) return 1;                                          // not a 16-bit value
-        const u64 ent = a.lut_ent[(size_t)o.aux * 65536 + x];              // (flat entry index << 16) | output, or ~0
-        if (ent == ~0ull) return 1;                                        // not in the table
-        r = ent & 0xFFFF;
-        atomicAdd(&mult[ent >> 16], 1u);
-    } else {
-        if (x == UNSET || y == UNSET) return 2;
-        if (kind == p2::OP_EQ)
-            r = x == y ? 1 : 0;
-        else
-            r = x == y ? 0 : gl::inv(gl::sub(x, y));
+__device__ __forceinline__ int witness_exec_macro(const WitnessArgs& a, u64* val, u32* mult, u32 proof, u32 ob, u32 cnt, const p2::Op& first, bool have_first) {
+    p2::Op o[WITNESS_KMAX];
+#pragma unroll
+    for (int i = 0; i < WITNESS_KMAX; i++)
+        if ((u32)i < cnt) o[i] = (i == 0 && have_first) ? first : a.ops[ob + i];
+    if (o[0].kind == p2::OP_POSEIDON) {  // a whole gate row; always alone in its macro
+        const int bad = HAS_POSEIDON ? witness_poseidon_op(a, val, proof, o[0]) : 0;
+        return bad == 0 ? 0 : bad == 1 ? 3 : 2;
     }
-    if (cur == UNSET)
-        val[o.out] = r;
-    else if (cur != r)
-        return 1;
-    return 0;
+    u64 x[WITNESS_KMAX], y[WITNESS_KMAX], z[WITNESS_KMAX], cur[WITNESS_KMAX], after[WITNESS_KMAX];
+#pragma unroll
+    for (int i = 0; i < WITNESS_KMAX; i++) {
+        x[i] = y[i] = z[i] = cur[i] = after[i] = 0;
+        if ((u32)i < cnt) {
+            const u32 kind = o[i].kind;
+            cur[i] = val[o[i].out];
+            if (kind != p2::OP_CONST) x[i] = val[o[i].a];
+            if (kind == p2::OP_ARITH || kind == p2::OP_EQ || kind == p2::OP_EQINV) y[i] = val[o[i].b];
+            if (kind == p2::OP_ARITH) z[i] = val[o[i].c];
+        }
+    }
+    int worst = 0;
+#pragma unroll
+    for (int i = 0; i < WITNESS_KMAX; i++) {
+        if ((u32)i >= cnt) break;
+        const u32 kind = o[i].kind;
+        // forwarding: the latest earlier op of this macro that wrote the slot decides (after[j] = the slot's value after op j)
+#pragma unroll
+        for (int j = 0; j < i; j++) {
+            if (o[j].out == o[i].a) x[i] = after[j];
+            if (o[j].out == o[i].b) y[i] = after[j];
+            if (o[j].out == o[i].c) z[i] = after[j];
+            if (o[j].out == o[i].out) cur[i] = after[j];
+        }
+        u64 r = 0;
+        int bad = 0;
+        if (kind == p2::OP_ARITH) {
+            if (x[i] == UNSET || y[i] == UNSET || z[i] == UNSET)
+                bad = 2;
+            else
+                r = gl::add(gl::mul(gl::mul(x[i], y[i]), o[i].k0), gl::mul(z[i], o[i].k1));
+        } else if (kind == p2::OP_CONST) {
+            r = o[i].k0;
+        } else if (kind == p2::OP_LOOKUP) {
+            if (x[i] == UNSET) {
+                bad = 2;
+            } else if (x[i] >= 65536) {  // not a 16-bit value
+                bad = 1;
+            } else {
+                const u64 ent = a.lut_ent[(size_t)o[i].aux * 65536 + x[i]];  // ONE load: (flat entry index << 16) | output, or ~0
+                if (ent == ~0ull) {
+                    bad = 1;  // not in the table
+                } else {
+                    r = ent & 0xFFFF;
+                    atomicAdd(&mult[ent >> 16], 1u);
+                }
+            }
+        } else {
+            if (x[i] == UNSET || y[i] == UNSET)
+                bad = 2;
+            else if (kind == p2::OP_EQ)
+                r = x[i] == y[i] ? 1 : 0;
+            else if (i == 0)  // an inverse hint is always alone in its macro: the Fermat inversion is compiled once, not KMAX times
+                r = x[i] == y[i] ? 0 : gl::inv(gl::sub(x[i], y[i]));
+            else
+                bad = 2;
+        }
+        after[i] = cur[i];
+        if (!bad) {
+            if (cur[i] == UNSET) {
+                val[o[i].out] = r;
+                after[i] = r;
+            } else if (cur[i] != r) {
+                bad = 1;
+            }
+        }
+        if (bad) worst = max(worst, bad == 1 ? 3 : 2);  // conflict (1) outranks missing input (2)
+    }
+    return worst;
 }
 
 // One workgroup generates one witness.  The program is scheduled (witness_schedule.h) into levels of MACROS: a macro is a short
-// straight-line run of ops that one thread executes in order (a later op of the run may read what an earlier one wrote: same
-// thread, program order), the macros of a level are independent, and a workgroup barrier separates the levels.  The
-// descriptors are shared by all proofs (L2-resident).
+// straight-line run of ops that one thread executes in order, the macros of a level are independent, and a workgroup barrier
+// separates the levels.  The descriptors are shared by all proofs (L2-resident).
 template <bool HAS_POSEIDON>
-__global__ __launch_bounds__(1024) void k_witness(WitnessArgs a) {
+__global__ __launch_bounds__(512) void k_witness(WitnessArgs a) {
     __shared__ int s_status;
     const u32 proof = blockIdx.x;
     u64* val = a.values + (size_t)proof * a.num_slots;
@@ -734,11 +914,7 @@ __global__ __launch_bounds__(1024) void k_witness(WitnessArgs a) {
         for (u32 m = beg + threadIdx.x; m < end; m += blockDim.x) {
             const bool pre = m == beg + threadIdx.x;
             const u32 ob = pre ? first_ob : a.macro_offsets[m], oe = pre ? first_oe : a.macro_offsets[m + 1];
-            for (u32 k = ob; k < oe; k++) {
-                const p2::Op o = (pre && k == ob) ? first : a.ops[k];
-                const int bad = witness_exec_op<HAS_POSEIDON>(a, val, mult, proof, o);
-                if (bad) worst = max(worst, bad == 1 ? 3 : 2);  // conflict (1) outranks missing input (2); remapped below
-            }
+            worst = max(worst, witness_exec_macro<HAS_POSEIDON>(a, val, mult, proof, ob, min(oe - ob, (u32)WITNESS_KMAX), first, pre));
         }
         if (worst) atomicMax(&s_status, worst);
         __syncthreads();

@@ -286,6 +286,43 @@ __global__ __launch_bounds__(256) void k_eval_polys(const u64* __restrict__ coef
     }
 }
 
+// The same for a LIST of polynomials from several oracles in one launch (round 2 launched the kernel above once per oracle and
+// point: preprocessed, wires, Z at zeta, Z at g zeta, quotient): entry e = column `col` of the coefficient matrix `base`,
+// evaluated with power table pw_k (0: zeta, 1: g zeta), result to extension slot `out`.
+struct EvalRef {
+    const u64* base;      // coefficient matrix of the oracle (proof 0)
+    size_t batch_stride;  // 0 for the shared preprocessed oracle
+    u32 col, pw_k, out, pad;
+};
+__global__ __launch_bounds__(256) void k_eval_polys_refs(const EvalRef* __restrict__ refs, const u64* __restrict__ pows /*[4][2][n]*/, size_t pw_batch_stride, u32 n,
+                                                          u64* __restrict__ ev, size_t ev_batch_stride) {
+    __shared__ u64 la[256], lb[256];
+    const EvalRef r = refs[blockIdx.x];
+    const u64* c = r.base + (size_t)blockIdx.y * r.batch_stride + (size_t)r.col * n;
+    const u64* pa = pows + (size_t)blockIdx.y * pw_batch_stride + (size_t)r.pw_k * 2 * n;
+    u64 sa = 0, sb = 0;
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+        u64 v = c[i];
+        sa = gl::add(sa, gl::mul(v, pa[i]));
+        sb = gl::add(sb, gl::mul(v, pa[n + i]));
+    }
+    la[threadIdx.x] = sa;
+    lb[threadIdx.x] = sb;
+    __syncthreads();
+    for (u32 off = blockDim.x / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            la[threadIdx.x] = gl::add(la[threadIdx.x], la[threadIdx.x + off]);
+            lb[threadIdx.x] = gl::add(lb[threadIdx.x], lb[threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        u64* o = ev + (size_t)blockIdx.y * ev_batch_stride + 2 * (size_t)r.out;
+        o[0] = la[0];
+        o[1] = lb[0];
+    }
+}
+
 // ------------------------------------------------------------------------------------------- FRI
 // Batch description: for each polynomial of a FRI batch, where its coefficient column lives.
 struct PolyRef {
@@ -434,6 +471,36 @@ __global__ void k_proof_gather_ext(const u64* src, size_t src_batch_stride, cons
     uint8_t* d = proofs + (size_t)blockIdx.y * proof_bytes + dst_off + 16 * (size_t)i;
     store_u64_bytes(d, s[0]);
     store_u64_bytes(d + 8, s[1]);
+}
+// Every fixed-position piece of the proof -- the caps, the opening set, the final polynomial, the PoW witness -- in ONE launch
+// (round 2: nine launches of the three kernels above).  blockIdx.z = piece.
+struct ProofSeg {
+    const u64* src;
+    const u32* map;       // kind 2: gather map
+    size_t src_batch_stride, comp_stride, dst_off;
+    u32 count, kind;      // 0: `count` words; 1: `count` extension elements from two component columns; 2: `count` gathered extension elements
+};
+struct ProofSegs {
+    ProofSeg s[12];
+    uint8_t* proofs;
+    size_t proof_bytes;
+};
+__global__ void k_proof_segments(ProofSegs a) {
+    const ProofSeg g = a.s[blockIdx.z];
+    const u64* s = g.src + (size_t)blockIdx.y * g.src_batch_stride;
+    uint8_t* d = a.proofs + (size_t)blockIdx.y * a.proof_bytes + g.dst_off;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < g.count; i += gridDim.x * blockDim.x) {
+        if (g.kind == 0) {
+            store_u64_bytes(d + 8 * (size_t)i, s[i]);
+        } else if (g.kind == 1) {
+            store_u64_bytes(d + 16 * (size_t)i, s[i]);
+            store_u64_bytes(d + 16 * (size_t)i + 8, s[g.comp_stride + i]);
+        } else {
+            const u64* e = s + 2 * (size_t)g.map[i];
+            store_u64_bytes(d + 16 * (size_t)i, e[0]);
+            store_u64_bytes(d + 16 * (size_t)i + 8, e[1]);
+        }
+    }
 }
 // component columns [2][len] -> interleaved (c0, c1) pairs
 __global__ void k_interleave_ext(const u64* src, size_t len, size_t src_batch_stride, u64* dst, size_t dst_batch_stride) {

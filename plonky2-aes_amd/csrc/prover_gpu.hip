@@ -59,6 +59,7 @@ struct Workspace {
     u32* d_pow_list = nullptr;  // [chunk] unsolved proofs + [1] their count (proof-of-work phases)
     uint8_t* d_proofs = nullptr;
     PolyRef* d_polyrefs = nullptr;
+    EvalRef* d_evalrefs = nullptr;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
 };
 
@@ -95,7 +96,7 @@ struct p2_circuit {
     Tree pre_tree;
     u64* d_digest = nullptr;  // circuit digest (4)
     std::vector<u64> verifier_data;
-    u32 n_b0 = 0, n_b1 = 0;
+    u32 n_b0 = 0, n_b1 = 0, n_evalrefs = 0;
     u32 *d_map_obs = nullptr, *d_map_ser = nullptr;
     u32 n_obs = 0, n_ser = 0, ev_count = 0;
     // ---- per-stream workspaces: chunks are dealt round-robin to streams so that the latency-bound stages of one
@@ -113,6 +114,9 @@ struct p2_circuit {
     // tuning options (p2_circuit_set_option; the environment is read ONCE, at load): proofs per chunk, proving streams,
     // phase timing of the host path on stderr
     size_t opt_chunk = 128, opt_streams = 2;
+    std::map<const u64*, u64*> pass1_out_tw;  // two-pass NTT: output-twiddle table per full twiddle table (ensure_pass1_table)
+    bool opt_merkle_top = true;               // P2AES_MERKLE_TOP=0: every level its own launch (A/B measurements)
+    bool opt_pass1_radix2 = false;            // P2AES_PASS1_RADIX2: the round-2 pass-1 kernel (A/B measurements)
     u32 opt_witness_fuse = 8;  // most ops per witness macro (P2AES_WITNESS_FUSE at load; 1 = one op per thread per level)
     bool opt_debug_timing = false;
     // host-path staging (p2_prove_batch): persistent device buffers + pinned host buffers, one set per concurrent caller
@@ -179,6 +183,17 @@ static int run_ntt(p2_circuit* C, const char* name, NttArgs a, u32 cols, u32 bat
     return 0;
 }
 static const u32 LDS_NTT_MAX_BITS = 14;  // whole transform in one workgroup's LDS up to 2^14 points
+// The output twiddles of pass 1 for the order-2^logn table `tw_full`, in output order (k_pass1_out_tw); built at load, never
+// while workspaces are open (allocations made then belong to the workspaces).
+static int ensure_pass1_table(p2_circuit* C, const u64* tw_full, u32 logn) {
+    if (logn <= LDS_NTT_MAX_BITS || C->pass1_out_tw.count(tw_full)) return 0;
+    u64* t = nullptr;
+    if (dalloc(C, &t, (size_t)1 << logn)) return P2_ERR_HIP;
+    hipLaunchKernelGGL(k_pass1_out_tw, g1((size_t)1 << logn, 256), dim3(256), 0, C->stream, tw_full, t, (int)logn, (int)(logn - 12));
+    HIPCHECK(hipGetLastError());
+    C->pass1_out_tw[tw_full] = t;
+    return 0;
+}
 // two-pass transform of `cols*cosets` blocks: natural order in `in`, bit-reversed order in `out`
 static int ntt_big(p2_circuit* C, const char* name, const u64* in, u64* out, const u64* tw_full, const u64* pre, u32 logn, u32 cols, u32 cosets,
                    const u32* block_of_coset, int in_coset_blocks, size_t in_col_stride, size_t out_col_stride, size_t in_batch_stride,
@@ -202,7 +217,13 @@ static int ntt_big(p2_circuit* C, const char* name, const u64* in, u64* out, con
     a.in_coset_blocks = in_coset_blocks;
     for (u32 j = 0; j < 8; j++) a.block_of_coset[j] = block_of_coset ? block_of_coset[j] : 0;
     u32 tiles = (1u << log_n2) >> log_T;
-    LAUNCH(C, name, k_ntt_pass1, dim3(tiles * cols * cosets, batch), dim3(256), (size_t)8 << 12, a);
+    auto it = C->pass1_out_tw.find(tw_full);
+    if (it == C->pass1_out_tw.end()) return set_error("internal: no pass-1 twiddle table for this transform"), P2_ERR_INVALID;
+    a.out_tw = it->second;
+    if (C->opt_pass1_radix2)
+        LAUNCH(C, name, k_ntt_pass1, dim3(tiles * cols * cosets, batch), dim3(256), (size_t)8 << 12, a);
+    else
+        LAUNCH(C, name, k_ntt_pass1_r16, dim3(tiles * cols * cosets, batch), dim3(256), r16_lds_bytes(12), a);
     // pass 2: every row of n2 contiguous points, in place
     if (out_col_stride != ((size_t)cosets << logn)) return set_error("internal: two-pass NTT needs densely packed output blocks"), P2_ERR_INVALID;
     NttArgs b{};
@@ -273,17 +294,28 @@ static int lde_cols(p2_circuit* C, const u64* coeffs, size_t in_batch_stride, u6
     for (u32 j = 0; j < 8; j++) a.block_of_coset[j] = blocks[j];
     return run_ntt(C, "lde", a, cols, batch);
 }
-static int merkle_build(p2_circuit* C, const u64* data, u32 cols, u32 active, size_t col_stride, size_t batch_stride, Tree& t, u32 batch) {
-    size_t leaves = (size_t)1 << t.bits;
-    LAUNCH(C, "hash_leaves", k_hash_leaves, g1(leaves, 256, batch), dim3(256), 0, data, (int)cols, (int)active, col_stride, batch_stride, leaves, t.dig,
-           t.stride());
-    for (u32 l = 0; l + C->c.cfg.cap_height < t.bits; l++) {
+// The levels above the leaf digests, up to the cap: wide levels one launch each, the top (at most 256 parents per cap
+// subtree, up to nine levels) in one launch of a workgroup per cap node.
+static int merkle_levels(p2_circuit* C, Tree& t, u32 batch) {
+    const u32 cap_h = C->c.cfg.cap_height;
+    if (t.bits <= cap_h) return 0;
+    const u32 levels = t.bits - cap_h;                       // level l: 2^(bits-l-1) parents
+    const u32 fused = C->opt_merkle_top ? std::min<u32>(levels, 9) : 0;  // the last `fused` levels: parents per cap subtree 2^(fused-1) .. 1
+    const size_t leaves = (size_t)1 << t.bits;
+    for (u32 l = 0; l < levels - fused; l++) {
         size_t parents = leaves >> (l + 1);
         size_t off_c = 4 * (((size_t)2 << t.bits) - ((size_t)2 << (t.bits - l)));
         size_t off_p = 4 * (((size_t)2 << t.bits) - ((size_t)2 << (t.bits - l - 1)));
         LAUNCH(C, "merkle_level", k_merkle_level, g1(parents, 256, batch), dim3(256), 0, t.dig + off_c, t.dig + off_p, parents, t.stride());
     }
+    if (fused) LAUNCH(C, "merkle_top", k_merkle_top, dim3(1u << cap_h, batch), dim3(256), 0, t.dig, t.stride(), t.bits, levels - fused, fused);
     return 0;
+}
+static int merkle_build(p2_circuit* C, const u64* data, u32 cols, u32 active, size_t col_stride, size_t batch_stride, Tree& t, u32 batch) {
+    size_t leaves = (size_t)1 << t.bits;
+    LAUNCH(C, "hash_leaves", k_hash_leaves, g1(leaves, 256, batch), dim3(256), 0, data, (int)cols, (int)active, col_stride, batch_stride, leaves, t.dig,
+           t.stride());
+    return merkle_levels(C, t, batch);
 }
 static size_t cap_off(const Tree& t, u32 cap_height) {
     u32 l = t.bits - cap_height;
@@ -315,7 +347,8 @@ static int circuit_setup(p2_circuit* C) {
     if (c.num_partial_products() + 1 > PERM_MAX_CHUNKS) return set_error("more partial-product chunks than k_perm_scan holds in registers"), P2_ERR_INVALID;
     {
         // the witness program, rescheduled for the device: levels of macros (witness_schedule.h)
-        WitnessSchedule ws = schedule_witness(c, C->opt_witness_fuse);
+        WitnessSchedule ws = schedule_witness(c, std::min<u32>(C->opt_witness_fuse, WITNESS_KMAX));
+        if (ws.max_macro > (u32)WITNESS_KMAX) return set_error("internal: witness macro larger than the kernel is unrolled for"), P2_ERR_INVALID;
         C->witness_levels = (u32)ws.level_offsets.size() - 1;
         C->witness_macros = (u32)ws.macro_offsets.size() - 1;
         if (upload(C, &C->d_ops, ws.ops.data(), ws.ops.size())) return P2_ERR_HIP;
@@ -366,6 +399,7 @@ static int circuit_setup(p2_circuit* C) {
         C->d_tw_fwd_full = C->d_subgroup;  // w^k, k < n
         C->d_tw_fwd = C->d_tw_fwd_full;    // the single-pass kernel only indexes k < n/2
         C->d_tw_inv = C->d_tw_inv_full;
+        if (ensure_pass1_table(C, C->d_tw_fwd_full, C->logn) || ensure_pass1_table(C, C->d_tw_inv_full, C->logn)) return P2_ERR_HIP;
         // FRI rounds whose polynomial is still > 2^14 need their own order-n_r table
         u32 logn_r = C->logn;
         for (u32 r = 0; r < C->arities.size(); r++) {
@@ -375,6 +409,7 @@ static int circuit_setup(p2_circuit* C) {
                 std::vector<u64> t(n_r);
                 for (size_t i = 0; i < n_r; i++) t[i] = sub[i << (C->logn - logn_r)];
                 if (upload(C, &C->d_tw_fwd_round[r + 1], t.data(), n_r)) return P2_ERR_HIP;
+                if (ensure_pass1_table(C, C->d_tw_fwd_round[r + 1], logn_r)) return P2_ERR_HIP;
             }
         }
     }
@@ -821,13 +856,7 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
     {
         const size_t evs = 2 * (size_t)C->ev_count;
         u64* ev = C->cur->d_ev;
-        LAUNCH(C, "eval_polys", k_eval_polys, dim3(np, B), dim3(256), 0, C->d_pre_coeffs, (size_t)0, C->cur->d_pows, (size_t)8 * n, (u32)n, ev, evs);
-        LAUNCH(C, "eval_polys", k_eval_polys, dim3(act, B), dim3(256), 0, C->cur->d_wcoef, ws, C->cur->d_pows, (size_t)8 * n, (u32)n, ev + 2 * (size_t)np, evs);
-        LAUNCH(C, "eval_polys", k_eval_polys, dim3(zc, B), dim3(256), 0, C->cur->d_zcoef, zs_s, C->cur->d_pows, (size_t)8 * n, (u32)n, ev + 2 * (size_t)(np + c.cfg.num_wires), evs);
-        LAUNCH(C, "eval_polys", k_eval_polys, dim3(zc, B), dim3(256), 0, C->cur->d_zcoef, zs_s, C->cur->d_pows + 2 * n, (size_t)8 * n, (u32)n,
-               ev + 2 * (size_t)(np + c.cfg.num_wires + zc), evs);
-        LAUNCH(C, "eval_polys", k_eval_polys, dim3(qc, B), dim3(256), 0, C->cur->d_qcoef, (size_t)qc * n, C->cur->d_pows, (size_t)8 * n, (u32)n,
-               ev + 2 * (size_t)(np + c.cfg.num_wires + 2 * zc), evs);
+        LAUNCH(C, "eval_polys", k_eval_polys_refs, dim3(C->n_evalrefs, B), dim3(256), 0, C->cur->d_evalrefs, C->cur->d_pows, (size_t)8 * n, (u32)n, ev, evs);
         LAUNCH(C, "gather_ext", k_gather_ext, g1(C->n_obs, 256, B), dim3(256), 0, C->cur->d_ev, evs, C->d_map_obs, C->n_obs, C->cur->d_obs, (size_t)2 * C->n_obs);
     }
     if (challenger(C, 3, C->cur->d_obs, (size_t)2 * C->n_obs, 2 * C->n_obs, 0, 0, B)) return P2_ERR_HIP;
@@ -844,12 +873,7 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
             Tree& t = C->cur->fri_tree[r];
             size_t leaves = len / arity;
             LAUNCH(C, "hash_fri_leaves", k_hash_fri_leaves, g1(leaves, 256, B), dim3(256), 0, C->cur->d_fri_vals[r], len, 2 * len, (int)arity, t.dig, t.stride());
-            for (u32 l = 0; l + cap_h < t.bits; l++) {
-                size_t parents = leaves >> (l + 1);
-                size_t off_c = 4 * (((size_t)2 << t.bits) - ((size_t)2 << (t.bits - l)));
-                size_t off_p = 4 * (((size_t)2 << t.bits) - ((size_t)2 << (t.bits - l - 1)));
-                LAUNCH(C, "merkle_level", k_merkle_level, g1(parents, 256, B), dim3(256), 0, t.dig + off_c, t.dig + off_p, parents, t.stride());
-            }
+            if (merkle_levels(C, t, B)) return P2_ERR_HIP;
             if (challenger(C, 4, t.dig + cap_off(t, cap_h), t.stride(), cap_words, r, 0, B)) return P2_ERR_HIP;
             size_t n_next = n_r >> C->arities[r];
             LAUNCH(C, "fri_fold", k_fri_fold, g1(n_next, 256, B), dim3(256), 0, C->cur->d_fri_coef[r], n_r, 2 * n_r, C->cur->d_fri_coef[r + 1], n_next, 2 * n_next, C->cur->d_chal, r,
@@ -879,15 +903,20 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         // 10. proof assembly
         size_t off = 0;
         const size_t pb = C->pbytes;
+        ProofSegs segs{};
+        u32 nseg = 0;
+        segs.proofs = d_proofs;
+        segs.proof_bytes = pb;
         for (Tree* t : {&C->cur->wtree, &C->cur->ztree, &C->cur->qtree}) {
-            LAUNCH(C, "proof_copy", k_proof_copy, g1(cap_words, 64, B), dim3(64), 0, t->dig + cap_off(*t, cap_h), t->stride(), cap_words, d_proofs, pb, off);
+            segs.s[nseg++] = ProofSeg{t->dig + cap_off(*t, cap_h), nullptr, t->stride(), 0, off, cap_words, 0};
             off += 8 * (size_t)cap_words;
         }
-        LAUNCH(C, "proof_gather", k_proof_gather_ext, g1(C->n_ser, 256, B), dim3(256), 0, C->cur->d_ev, 2 * (size_t)C->ev_count, C->d_map_ser, C->n_ser, d_proofs, pb, off);
+        segs.s[nseg++] = ProofSeg{C->cur->d_ev, C->d_map_ser, 2 * (size_t)C->ev_count, 0, off, C->n_ser, 2};
         off += 16 * (size_t)C->n_ser;
+        if (R_ + 6 > 12) return set_error("internal: more FRI rounds than proof segments"), P2_ERR_INVALID;
         for (u32 r = 0; r < R_; r++) {
             Tree& t = C->cur->fri_tree[r];
-            LAUNCH(C, "proof_copy", k_proof_copy, g1(cap_words, 64, B), dim3(64), 0, t.dig + cap_off(t, cap_h), t.stride(), cap_words, d_proofs, pb, off);
+            segs.s[nseg++] = ProofSeg{t.dig + cap_off(t, cap_h), nullptr, t.stride(), 0, off, cap_words, 0};
             off += 8 * (size_t)cap_words;
         }
         QueryArgs q{};
@@ -928,11 +957,12 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         q.query_bytes = qbytes;
         LAUNCH(C, "write_queries", k_write_queries, dim3(c.cfg.num_query_rounds, B), dim3(256), 0, q);
         off += qbytes * c.cfg.num_query_rounds;
-        LAUNCH(C, "proof_copy_ext", k_proof_copy_ext, g1(fl, 64, B), dim3(64), 0, C->cur->d_fri_coef[R_], 2 * fl, fl, (u32)fl, d_proofs, pb, off);
+        segs.s[nseg++] = ProofSeg{C->cur->d_fri_coef[R_], nullptr, 2 * fl, fl, off, (u32)fl, 1};
         off += 16 * fl;
-        LAUNCH(C, "proof_copy", k_proof_copy, g1(1, 64, B), dim3(64), 0, C->cur->d_chal + CH_POW, (size_t)CH_WORDS, 1u, d_proofs, pb, off);
+        segs.s[nseg++] = ProofSeg{C->cur->d_chal + CH_POW, nullptr, (size_t)CH_WORDS, 0, off, 1u, 0};
         off += 8;
         if (off != pb) return set_error("internal: proof layout size mismatch"), P2_ERR_INVALID;
+        LAUNCH(C, "proof_segments", k_proof_segments, dim3(2, B, nseg), dim3(256), 0, segs);
     }
     LAUNCH(C, "finish", k_finish, g1(C->pbytes, 256, B), dim3(256), 0, C->cur->d_status, d_status_out, d_proofs, C->pbytes, B);
     return 0;
@@ -1056,6 +1086,8 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
         // environment defaults for the options, read once here (never per call)
         if (const char* e = getenv("P2AES_CHUNK")) C->opt_chunk = (size_t)std::max(1, atoi(e));
         if (const char* e = getenv("P2AES_STREAMS")) C->opt_streams = (size_t)std::min(8, std::max(1, atoi(e)));
+        C->opt_pass1_radix2 = getenv("P2AES_PASS1_RADIX2") != nullptr;
+        if (const char* e = getenv("P2AES_MERKLE_TOP")) C->opt_merkle_top = atoi(e) != 0;
         if (const char* e = getenv("P2AES_WITNESS_FUSE")) C->opt_witness_fuse = (u32)std::min(1024, std::max(1, atoi(e)));
         C->opt_debug_timing = getenv("P2AES_DEBUG_TIMING") != nullptr;
         if (const char* e = getenv("P2AES_TEST_FAIL_ALLOC_AFTER")) C->fail_alloc_after = atol(e);
@@ -1067,7 +1099,8 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
             hipFuncSetAttribute((const void*)k_ntt_r16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r16_lds_bytes(14)) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_ntt_r16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r16_lds_bytes(13)) != hipSuccess)
             throw std::runtime_error("cannot raise the dynamic LDS limit for the NTT kernels");
-        if (hipFuncSetAttribute((const void*)k_ntt_pass1, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_ntt_pass1, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_ntt_pass1_r16, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
             throw std::runtime_error("cannot set the dynamic LDS limit of the pass-1 NTT");
         // opening maps
         const u32 np = c.num_preprocessed(), W = c.cfg.num_wires, zc = c.num_zs_cols(), qc = c.num_quotient_cols(), NC = c.cfg.num_challenges;
@@ -1156,6 +1189,15 @@ static int setup_polyrefs(p2_circuit* C) {
     for (u32 i = 0; i < NC; i++) v.push_back({C->cur->d_zcoef, (size_t)zc * n, i, 0});
     for (u32 i = nzpp; i < zc; i++) v.push_back({C->cur->d_zcoef, (size_t)zc * n, i, 0});
     C->n_b1 = (u32)v.size() - C->n_b0;
+    // the opening set: every polynomial at zeta, the Z columns at g zeta as well (slots: preprocessed | wires | Z(zeta) | Z(g zeta) | quotient)
+    std::vector<EvalRef> e;
+    for (u32 i = 0; i < np; i++) e.push_back({C->d_pre_coeffs, 0, i, 0, i, 0});
+    for (u32 i = 0; i < C->active_wires; i++) e.push_back({C->cur->d_wcoef, (size_t)C->active_wires * n, i, 0, np + i, 0});
+    for (u32 i = 0; i < zc; i++) e.push_back({C->cur->d_zcoef, (size_t)zc * n, i, 0, np + W + i, 0});
+    for (u32 i = 0; i < zc; i++) e.push_back({C->cur->d_zcoef, (size_t)zc * n, i, 1, np + W + zc + i, 0});
+    for (u32 i = 0; i < qc; i++) e.push_back({C->cur->d_qcoef, (size_t)qc * n, i, 0, np + W + 2 * zc + i, 0});
+    C->n_evalrefs = (u32)e.size();
+    if (upload(C, &C->cur->d_evalrefs, e.data(), e.size())) return P2_ERR_HIP;
     return upload(C, &C->cur->d_polyrefs, v.data(), v.size());
 }
 
@@ -1579,6 +1621,8 @@ struct PrimCtx {
         if (upload(&C, &C.d_tw_fwd_full, twf.data(), n) || upload(&C, &C.d_tw_inv_full, twi.data(), n)) return P2_ERR_HIP;
         C.d_tw_fwd = C.d_tw_fwd_full;
         C.d_tw_inv = C.d_tw_inv_full;
+        if (ensure_pass1_table(&C, C.d_tw_fwd_full, (u32)degree_bits) || ensure_pass1_table(&C, C.d_tw_inv_full, (u32)degree_bits)) return P2_ERR_HIP;
+        C.opt_pass1_radix2 = getenv("P2AES_PASS1_RADIX2") != nullptr;
         std::vector<u64> bases(8);
         u64 wl = gl::root_of_unity(degree_bits + 3);
         for (u32 j = 0; j < 8; j++) bases[j] = gl::mul(gl::MULT_GEN, gl::pow(wl, j));

@@ -50,10 +50,12 @@ def test_poseidon_permutation(gpu, orc):
         assert list(s) == list(buf[12 * i:12 * i + 12])
 
 
-@pytest.mark.parametrize("bits", [1, 2, 4, 7, 11, 14, 15, 17])
+@pytest.mark.parametrize("bits", [1, 2, 4, 7, 11, 14, 15, 16, 17, 18, 19])
 def test_intt_and_lde(gpu, orc, bits):
     r = random.Random(bits)
-    cols, n = (5 if bits <= 14 else 2), 1 << bits   # > 14 bits exercises the two-pass (four-step) transform
+    # > 14 bits exercises the two-pass (four-step) transform; 15..19 cover every shape of its register-blocked first pass
+    # (3, 4, 1 + 4, 2 + 4 and 3 + 4 stages down the rows of a tile)
+    cols, n = (5 if bits <= 14 else 2 if bits <= 17 else 1), 1 << bits
     vals = [r.randrange(P) for _ in range(cols * n)]
     if cols > 2:
         vals[:n] = [0] * n                       # an all-zero column
