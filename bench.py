@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_TAG = "r02"     # profiles/<tag>_traffic.json (PMC bytes) and profiles/<tag>_valu.json (PMC VALU instructions) of this round
+PROFILE_TAG = "r03"     # profiles/<tag>_traffic.json (PMC bytes) and profiles/<tag>_valu.json (PMC VALU instructions) of this round
 NUM_SIMD, LANES_PER_CYCLE = 256 * 4, 32  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles
 
 
@@ -290,11 +290,28 @@ def main():
             kb = kernel_bytes(dom, info)
             nbytes = kb * chunk if kb else None
         avg_ms = ms / cnt
+        # The counter files are evidence taken on ONE build: each records the identity of the kernel sources it was measured on
+        # (tools/src_id.py) and is used only while that matches the sources this run is built from -- otherwise the field is
+        # null and *_source says "stale", instead of silently pricing another binary.
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from src_id import csrc_id
+        here = csrc_id()["csrc_sha16"]
+
+        def profile(kind):
+            path = os.path.join("profiles", PROFILE_TAG + "_" + kind + ".json")
+            try:
+                j = json.load(open(os.path.join(ROOT, path)))
+            except Exception:  # noqa: BLE001
+                return None, {"file": path, "status": "missing"}
+            src = j.get("source", {})
+            ok = src.get("csrc_sha16") == here
+            return (j if ok else None), {"file": path, "measured_on_csrc_sha16": src.get("csrc_sha16"), "git_head": src.get("git_head"), "this_build_csrc_sha16": here,
+                                         "status": "current" if ok else "stale: measured on other kernel sources"}
         traffic = None
+        tj, traffic_source = profile("traffic")
         try:  # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x2 per calibration, WRITE_SIZE), profiles/
-            tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_traffic.json")))
-            key = {"hash_leaves": "k_hash_leaves", "lde": "k_ntt_lds", "quotient": "k_quotient<false>"}.get(dom)
-            if key and L == 1024 and chunk == tj.get("chunk") and args.workload == "aes-gcm":
+            key = {"hash_leaves": "k_hash_leaves", "lde": "k_ntt_r16<true>", "quotient": "k_quotient<false>"}.get(dom)
+            if tj and key and L == 1024 and chunk == tj.get("chunk") and args.workload == "aes-gcm":
                 ent = tj["per_launch_avg_bytes"][key]
                 traffic = ent.get("chunk_launches_avg", ent["total"])
         except Exception:  # noqa: BLE001
@@ -302,16 +319,17 @@ def main():
         if nbytes:
             ach = nbytes / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(avg_ms, 4),
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(avg_ms, 4),
                         "share_of_gpu_time": round(ms / total, 3),
                         "note": "kernel is VALU-issue bound (a Poseidon permutation is 15.5 k VALU instructions), not HBM bound: see roofline_valu and DESIGN.md section 5",
                         "poseidon_perm_per_s": round((24 * (8 << info["degree_bits"]) * chunk / 3.0) / (avg_ms * 1e-3)) if dom == "hash_leaves" else None}
         # The roofline that actually bounds the path: VALU issue.  Instruction counts per launch are a property of the
         # kernel and the workload (rocprofv3 --pmc SQ_INSTS_VALU, profiles/<tag>_valu.json via tools/pmc_valu.py); the
         # duration is this run's own HIP-event measurement; the clock is the one the chip held in the counter pass.
+        vjj, valu_source = profile("valu")
         try:
-            vj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_valu.json")))["kernels"]
-            key = {"hash_leaves": "k_hash_leaves", "lde": "k_ntt_lds", "quotient": "k_quotient<false>"}.get(dom)
+            vj = vjj["kernels"] if vjj else {}
+            key = {"hash_leaves": "k_hash_leaves", "lde": "k_ntt_r16<true>", "quotient": "k_quotient<false>"}.get(dom)
             if key in vj and L == 1024 and args.workload == "aes-gcm" and chunk == 128:
                 e = vj[key]
                 clock = e["clock_GHz"] * 1e9
@@ -319,13 +337,15 @@ def main():
                 peak = NUM_SIMD * LANES_PER_CYCLE * clock
                 perms = 24 * (8 << info["degree_bits"]) * chunk / 3.0
                 roofline_valu = {"bound": "valu_issue", "kernel": dom, "achieved": round(ach / 1e12, 2), "peak": round(peak / 1e12, 2), "unit": "T lane-ops/s",
-                                 "frac": round(ach / peak, 4), "clock_GHz": e["clock_GHz"], "valu_insts_per_launch": e["valu_insts"],
+                                 "frac": round(ach / peak, 4), "clock_GHz": e["clock_GHz"], "valu_insts_per_launch": e["valu_insts"], "valu_source": valu_source,
                                  "insts_per_perm": round(e["valu_insts"] * 64 / perms) if dom == "hash_leaves" else None,
                                  "cycles_per_inst": round(NUM_SIMD * clock * avg_ms * 1e-3 / e["valu_insts"], 3),
                                  "note": "peak = 256 CU x 4 SIMD x 32 lanes x clock (one wave64 instruction per 2 cycles); tools/microbench/valu_rates.hip measures 2.3 cycles for "
                                          "plain two-source ops and 4.1 for v_mad_u64_u32 / carry / select / three-source ops, so this instruction mix cannot exceed ~0.6"}
         except Exception:  # noqa: BLE001
             roofline_valu = None
+        if roofline_valu is None and L == 1024 and args.workload == "aes-gcm":
+            roofline_valu = {"bound": "valu_issue", "kernel": dom, "achieved": None, "valu_source": valu_source}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU baseline is reported at N = 1 only

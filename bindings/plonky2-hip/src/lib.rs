@@ -267,7 +267,9 @@ pub mod plonk {
             pub fn connect(&mut self, x: Target, y: Target) { unsafe { ffi::p2_builder_connect(self.h, x.0, y.0) } }              // :163
             /// circuit_aes.rs:300,317,334; circuit_gcm.rs:396,415.  `(u16, u16)` is two adjacent u16 in memory.
             pub fn add_lookup_table_from_pairs(&mut self, table: Arc<Vec<(u16, u16)>>) -> usize {
-                unsafe { ffi::p2_builder_add_lookup_table_from_pairs(self.h, table.as_ptr() as *const u16, table.len()) }
+                // (u16, u16) has no guaranteed layout (repr(Rust)): flatten to the [in, out, in, out, ...] array the C ABI reads
+                let flat: Vec<u16> = table.iter().flat_map(|&(a, b)| [a, b]).collect();
+                unsafe { ffi::p2_builder_add_lookup_table_from_pairs(self.h, flat.as_ptr(), table.len()) }
             }
             /// circuit_aes.rs:182,193,250,357; circuit_gcm.rs:403,424.
             pub fn add_lookup_from_index(&mut self, looking_in: Target, lut_index: usize) -> Target {
@@ -325,7 +327,13 @@ pub mod pod2 {
         pub fn group_order() -> [u64; 5] { let mut o = [0u64; 5]; unsafe { ffi::p2_ecgfp5_group_order(o.as_mut_ptr()) }; o }
         impl Point {
             pub fn generator() -> Self { let mut o = [0u64; 10]; unsafe { ffi::p2_ecgfp5_generator(o.as_mut_ptr()) }; unpack(o) }
-            pub fn new_rand_from_subgroup() -> Self { let mut o = [0u64; 10]; unsafe { ffi::p2_ecgfp5_random_point(o.as_mut_ptr()) }; unpack(o) }
+            pub fn new_rand_from_subgroup() -> Self {
+                let mut o = [0u64; 10];
+                // OS randomness can fail: an all-zero buffer must never pass for a random point or key
+                let rc = unsafe { ffi::p2_ecgfp5_random_point(o.as_mut_ptr()) };
+                assert!(rc == ffi::P2_OK, "{}", crate::last_error());
+                unpack(o)
+            }
             pub fn as_fields(&self) -> Vec<u64> { pack(self).to_vec() }
             pub fn inverse(&self) -> Self { let mut o = [0u64; 10]; unsafe { ffi::p2_ecgfp5_neg(pack(self).as_ptr(), o.as_mut_ptr()) }; unpack(o) }   // elgamal.rs:21
             pub fn is_in_subgroup(&self) -> bool { unsafe { ffi::p2_ecgfp5_is_in_subgroup(pack(self).as_ptr()) == 1 } }

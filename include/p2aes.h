@@ -196,9 +196,10 @@ typedef struct {
 } p2_circuit_info;
 int p2_blob_info(const uint8_t* blob, size_t len, p2_circuit_info* out);
 /* The device-side schedule of a compiled circuit's witness program for macro size `fuse` (csrc/witness_schedule.h; the prover
- * builds it at p2_circuit_load with P2AES_WITNESS_FUSE, default 8), computed AND checked on the host, no device needed:
+ * builds it at p2_circuit_load; P2AES_WITNESS_FUSE, default and maximum 8), computed AND checked on the host, no device needed:
  * every op is kept, every slot keeps its first producer, and every operand of every op is produced in an earlier level
- * or earlier in the op's own macro.  out = {levels, macros, largest macro, ops}.  P2_ERR_INVALID if a check fails. */
+ * or earlier in the op's own chain.  out = {levels, chains, longest chain, ops fused into chains}.  P2_ERR_INVALID if a
+ * check fails. */
 int p2_witness_schedule_check(const uint8_t* blob, size_t len, uint32_t fuse, uint32_t out[4]);
 /* verifier_data = constants_sigmas_cap (16 digests) || circuit_digest, 68 u64 -- from p2_circuit_verifier_data */
 int p2_verify(const uint8_t* blob, size_t blob_len, const uint64_t* verifier_data, size_t verifier_data_len,
@@ -213,9 +214,11 @@ int p2_circuit_verifier_data(const p2_circuit*, uint64_t* out, size_t cap, size_
 /* zk circuits only.  Blinding values are the output of a Poseidon-based PRF under a 256-bit key (four field elements)
  * and a per-handle proof counter that advances with every proof attempted.  The key is drawn from the operating system's
  * CSPRNG at load time (upstream: OS randomness per proof) -- that is the production path and needs no call here.
- * TEST ONLY: p2_circuit_set_zk_key fixes the key (words are reduced mod p) and resets the counter, which makes proofs
- * reproducible so the CPU oracle can check them byte for byte; p2_circuit_set_zk_seed(s) is set_zk_key({s, 0, 0, 0}).
- * A fixed key is not secret: never use either outside tests and benchmarks. */
+ * TEST ONLY: p2_circuit_set_zk_key fixes the key (words are reduced mod p) and, when the key differs from the one the handle
+ * holds, restarts the counter -- which makes proofs reproducible so the CPU oracle can check them byte for byte;
+ * p2_circuit_set_zk_seed(s) is set_zk_key({s, 0, 0, 0}).  Both return P2_ERR_INVALID unless the environment holds
+ * P2AES_ALLOW_FIXED_ZK_KEY=1 (the test suite sets it).  A fixed key is not secret, and one key on two handles (or set again
+ * after proofs were made under another) blinds different witnesses with the same values: never outside tests. */
 int p2_circuit_set_zk_key(p2_circuit*, const uint64_t key[4]);
 int p2_circuit_set_zk_seed(p2_circuit*, uint64_t seed);
 size_t p2_circuit_proof_bytes(const p2_circuit*);

@@ -396,11 +396,11 @@ class CircuitData:
 
     def witness_schedule(self, fuse=8):
         """Host-side check of the device's witness schedule for macro size `fuse` (csrc/witness_schedule.h):
-        {levels, macros, max_macro, ops}; raises if an operand would not be ready when its op runs."""
+        {levels, chains, max_chain, fused_ops}; raises if an operand would not be ready when its op runs."""
         out = (C.c_uint32 * 4)()
         if lib().p2_witness_schedule_check(self.blob, len(self.blob), fuse, out):
             raise P2Error(_err())
-        return dict(zip(("levels", "macros", "max_macro", "ops"), out))
+        return dict(zip(("levels", "chains", "max_chain", "fused_ops"), out))
 
     def verifier_data(self):
         """constants_sigmas_cap || circuit_digest.  Computed on the device when the circuit is loaded (the reference's

@@ -533,8 +533,31 @@ int p2_witness_schedule_check(const uint8_t* blob, size_t len, uint32_t fuse, ui
             }
             return nd;
         };
-        if (s.ops.size() != M || s.macro_offsets.empty() || s.macro_offsets.back() != M || s.level_offsets.back() + 1 != s.macro_offsets.size())
-            return set_error("witness schedule: shape"), P2_ERR_INVALID;
+        if (s.ops.size() != M || s.levels.empty()) return set_error("witness schedule: shape"), P2_ERR_INVALID;
+        // every op belongs to exactly one unit (a chain or a single) of exactly one level, and the levels tile the op array
+        const u32 NONE = ~0u;
+        std::vector<u32> unit_of(M, NONE), level_of(M, NONE);
+        u32 cursor = 0, unit = 0, chain_cursor = 0;
+        for (size_t l = 0; l < s.levels.size(); l++) {
+            const WLevel& L = s.levels[l];
+            if (L.chain_begin != chain_cursor || (size_t)L.chain_begin + L.chain_count > s.chains.size()) return set_error("witness schedule: chain ranges"), P2_ERR_INVALID;
+            for (u32 ci = 0; ci < L.chain_count; ci++) {
+                const WChain& ch = s.chains[L.chain_begin + ci];
+                if (ch.start != cursor || ch.count < 2 || ch.count > std::max<u32>(fuse, 1) || (size_t)ch.start + ch.count > M) return set_error("witness schedule: chain shape"), P2_ERR_INVALID;
+                for (u32 k = 0; k < ch.count; k++) {
+                    const u32 kind = s.ops[ch.start + k].kind;
+                    if (kind != OP_ARITH && kind != OP_CONST && kind != OP_EQ) return set_error("witness schedule: a chain holds an op the chain executor does not run"), P2_ERR_INVALID;
+                    unit_of[ch.start + k] = unit, level_of[ch.start + k] = (u32)l;
+                }
+                unit++;
+                cursor += ch.count;
+            }
+            chain_cursor += L.chain_count;
+            if (L.single_begin != cursor || L.single_end < L.single_begin || L.single_end > M) return set_error("witness schedule: single ranges"), P2_ERR_INVALID;
+            for (u32 k = L.single_begin; k < L.single_end; k++) unit_of[k] = unit++, level_of[k] = (u32)l;
+            cursor = L.single_end;
+        }
+        if (cursor != M || chain_cursor != s.chains.size()) return set_error("witness schedule: the levels do not tile the program"), P2_ERR_INVALID;
         // first producer of every slot, in the builder's order and in the scheduled order
         std::vector<int64_t> first_orig(c.num_slots, -1), first_sched(c.num_slots, -1);
         u32 d[96];
@@ -543,14 +566,6 @@ int p2_witness_schedule_check(const uint8_t* blob, size_t len, uint32_t fuse, ui
             int nd = slots_of(c.ops[i], d, fo);
             for (int j = fo; j < nd; j++)
                 if (first_orig[d[j]] < 0) first_orig[d[j]] = (int64_t)i;
-        }
-        std::vector<u32> macro_of(M), level_of_macro(s.macro_offsets.size() - 1);
-        for (size_t l = 0; l + 1 < s.level_offsets.size(); l++)
-            for (u32 m = s.level_offsets[l]; m < s.level_offsets[l + 1]; m++) level_of_macro[m] = (u32)l;
-        for (size_t m = 0; m + 1 < s.macro_offsets.size(); m++) {
-            if (s.macro_offsets[m + 1] <= s.macro_offsets[m] || s.macro_offsets[m + 1] - s.macro_offsets[m] > std::max<u32>(fuse, 1))
-                return set_error("witness schedule: empty or oversized macro"), P2_ERR_INVALID;
-            for (u32 k = s.macro_offsets[m]; k < s.macro_offsets[m + 1]; k++) macro_of[k] = (u32)m;
         }
         for (size_t i = 0; i < M; i++) {
             int nd = slots_of(s.ops[i], d, fo);
@@ -566,9 +581,9 @@ int p2_witness_schedule_check(const uint8_t* blob, size_t len, uint32_t fuse, ui
             for (int j = 0; j < nd; j++) {
                 const int64_t p = first_sched[d[j]];
                 if (p < 0 || p == (int64_t)i) continue;   // a user input, or this op is the producer
-                const bool earlier_level = level_of_macro[macro_of[p]] < level_of_macro[macro_of[i]];
-                const bool same_macro_before = macro_of[p] == macro_of[i] && p < (int64_t)i;
-                if (!earlier_level && !same_macro_before) return set_error("witness schedule: an operand is not ready when its op runs"), P2_ERR_INVALID;
+                const bool earlier_level = level_of[p] < level_of[i];
+                const bool same_unit_before = unit_of[p] == unit_of[i] && p < (int64_t)i;
+                if (!earlier_level && !same_unit_before) return set_error("witness schedule: an operand is not ready when its op runs"), P2_ERR_INVALID;
             }
         }
         // multiset of ops preserved: compare sorted fingerprints
@@ -578,10 +593,10 @@ int p2_witness_schedule_check(const uint8_t* blob, size_t len, uint32_t fuse, ui
         std::sort(fa.begin(), fa.end());
         std::sort(fb.begin(), fb.end());
         if (fa != fb) return set_error("witness schedule: ops changed"), P2_ERR_INVALID;
-        out[0] = (u32)s.level_offsets.size() - 1;
-        out[1] = (u32)s.macro_offsets.size() - 1;
-        out[2] = s.max_macro;
-        out[3] = (u32)M;
+        out[0] = (u32)s.levels.size();
+        out[1] = (u32)s.chains.size();
+        out[2] = s.max_chain;
+        out[3] = (u32)s.fused_ops;
         return P2_OK;
     } catch (std::exception& e) {
         return set_error(e.what()), P2_ERR_INVALID;

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "circuit.h"
+#include "witness_schedule.h"
 #include "gl.h"
 #include "poseidon_fast.h"
 #include "poseidon_gate.h"
@@ -535,7 +536,7 @@ struct Pass1Args {
     const u64* pre;  // [cosets][n] scale applied on load, or null
     const u64* out_tw;  // k_ntt_pass1_r16: [n1][n2] w^(rev(row) j2), the output twiddle in output order
     size_t in_col_stride, out_col_stride, in_batch_stride, out_batch_stride;
-    int logn, log_n1, log_T, cosets, in_coset_blocks;
+    int logn, log_n1, log_T, cosets, in_coset_blocks, xcd_swizzle;
     u32 block_of_coset[8];
 };
 __global__ __launch_bounds__(256) void k_ntt_pass1(Pass1Args a) {
@@ -600,7 +601,8 @@ __global__ __launch_bounds__(256, 4) void k_ntt_pass1_r16(Pass1Args a) {
     const u32 T = 1u << a.log_T, t = threadIdx.x;
     const int log_n2 = a.logn - a.log_n1;
     const u32 n2 = 1u << log_n2, tiles = n2 >> a.log_T;
-    const u32 bid = xcd_swizzle(blockIdx.x, gridDim.x);  // the 8 cosets of one (column, tile) read the same input: one XCD, one L2
+    // the 8 cosets of one (column, tile) read the same input: one XCD, one L2 (a.xcd_swizzle; off when there is one coset)
+    const u32 bid = a.xcd_swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
     const u32 tile = bid % tiles, cc = bid / tiles, col = cc / a.cosets, coset = cc % a.cosets;
     const u32 blk = a.block_of_coset[coset];
     const size_t n = (size_t)1 << a.logn;
@@ -719,8 +721,8 @@ __global__ void k_quotient_chunks_rev(const u64* __restrict__ r, u64* __restrict
 // ------------------------------------------------------------------------------------------- witness
 struct WitnessArgs {
     const p2::Op* ops;            // scheduled order (witness_schedule.h)
-    const u32* macro_offsets;     // macro m = ops[macro_offsets[m], macro_offsets[m + 1])
-    const u32* level_offsets;     // level l = macros [level_offsets[l], level_offsets[l + 1])
+    const p2::WLevel* levels;     // per level: its chains and its single ops
+    const p2::WChain* chains;
     u32 num_levels, num_slots, n_inputs;
     const u32* input_slots;   // [n_inputs] (shared by the batch)
     const u64* input_values;  // [batch][n_inputs]
@@ -761,29 +763,26 @@ __device__ __noinline__ int witness_poseidon_op(const WitnessArgs& a, u64* val, 
     return bad;
 }
 
-// Most ops per macro the kernel is unrolled for (witness_schedule.h caps the schedule at this).
+// Most ops per chain the kernel is unrolled for (witness_schedule.h is asked for chains no longer than this).
 static const int WITNESS_KMAX = 8;
+// Single ops a thread keeps in flight together: the kernel is latency bound (a dependent chain of memory round trips per op,
+// one workgroup per proof), so what it processes per unit time is (threads x ops in flight) / round-trip time.
+static const int WITNESS_MLP = 4;
 
-// One MACRO of the witness program: up to WITNESS_KMAX ops that one thread runs in order (witness_schedule.h).  What a level
-// costs is its chain of dependent memory round trips (a microsecond or more each: the slot array of a 2^19-row circuit is
-// 85 MB per proof, the descriptors stream from HBM), not its arithmetic, so the macro is arranged to need as few as possible:
-//   1. all descriptors of the macro (contiguous);
+// One CHAIN of the witness program: up to WITNESS_KMAX lookup-free ops (ARITH, CONST, EQ) that one thread runs in order
+// (witness_schedule.h).  What a level costs is its chain of dependent memory round trips, not its arithmetic, so the chain is
+// arranged to need two however long it is:
+//   1. all descriptors of the chain (contiguous);
 //   2. every operand of every op, and the present value of every output slot, TOGETHER -- whether or not an earlier op of
-//      the macro is about to produce it;
-//   3. the ops in order, an operand that an earlier op of the macro produced taken from that op's result in registers
-//      (forwarding) instead of from memory; only a table lookup whose input is computed inside the macro adds a round trip.
-// A carry chain (inc32: add, is_equal, mul, select, select, next byte ...) thus costs two round trips per macro instead of
-// two per op.  Returns 0 ok, 2 missing input, 3 conflict / lookup miss (the encoding of s_status).
-template <bool HAS_POSEIDON>
-__device__ __forceinline__ int witness_exec_macro(const WitnessArgs& a, u64* val, u32* mult, u32 proof, u32 ob, u32 cnt, const p2::Op& first, bool have_first) {
+//      the chain is about to produce it;
+//   3. the ops in order, an operand that an earlier op of the chain produced taken from that op's result in registers
+//      (forwarding) instead of from memory.
+// Returns 0 ok, 2 missing input, 3 conflict (the encoding of s_status).
+__device__ __forceinline__ int witness_exec_chain(const WitnessArgs& a, u64* val, u32 ob, u32 cnt) {
     p2::Op o[WITNESS_KMAX];
 #pragma unroll
     for (int i = 0; i < WITNESS_KMAX; i++)
-        if ((u32)i < cnt) o[i] = (i == 0 && have_first) ? first : a.ops[ob + i];
-    if (o[0].kind == p2::OP_POSEIDON) {  // a whole gate row; always alone in its macro
-        const int bad = HAS_POSEIDON ? witness_poseidon_op(a, val, proof, o[0]) : 0;
-        return bad == 0 ? 0 : bad == 1 ? 3 : 2;
-    }
+        if ((u32)i < cnt) o[i] = a.ops[ob + i];
     u64 x[WITNESS_KMAX], y[WITNESS_KMAX], z[WITNESS_KMAX], cur[WITNESS_KMAX], after[WITNESS_KMAX];
 #pragma unroll
     for (int i = 0; i < WITNESS_KMAX; i++) {
@@ -792,7 +791,7 @@ __device__ __forceinline__ int witness_exec_macro(const WitnessArgs& a, u64* val
             const u32 kind = o[i].kind;
             cur[i] = val[o[i].out];
             if (kind != p2::OP_CONST) x[i] = val[o[i].a];
-            if (kind == p2::OP_ARITH || kind == p2::OP_EQ || kind == p2::OP_EQINV) y[i] = val[o[i].b];
+            if (kind != p2::OP_CONST) y[i] = val[o[i].b];
             if (kind == p2::OP_ARITH) z[i] = val[o[i].c];
         }
     }
@@ -801,7 +800,7 @@ __device__ __forceinline__ int witness_exec_macro(const WitnessArgs& a, u64* val
     for (int i = 0; i < WITNESS_KMAX; i++) {
         if ((u32)i >= cnt) break;
         const u32 kind = o[i].kind;
-        // forwarding: the latest earlier op of this macro that wrote the slot decides (after[j] = the slot's value after op j)
+        // forwarding: the latest earlier op of this chain that wrote the slot decides (after[j] = the slot's value after op j)
 #pragma unroll
         for (int j = 0; j < i; j++) {
             if (o[j].out == o[i].a) x[i] = after[j];
@@ -818,29 +817,13 @@ __device__ __forceinline__ int witness_exec_macro(const WitnessArgs& a, u64* val
                 r = gl::add(gl::mul(gl::mul(x[i], y[i]), o[i].k0), gl::mul(z[i], o[i].k1));
         } else if (kind == p2::OP_CONST) {
             r = o[i].k0;
-        } else if (kind == p2::OP_LOOKUP) {
-            if (x[i] == UNSET) {
-                bad = 2;
-            } else if (x[i] >= 65536) {  // not a 16-bit value
-                bad = 1;
-            } else {
-                const u64 ent = a.lut_ent[(size_t)o[i].aux * 65536 + x[i]];  // ONE load: (flat entry index << 16) | output, or ~0
-                if (ent == ~0ull) {
-                    bad = 1;  // not in the table
-                } else {
-                    r = ent & 0xFFFF;
-                    atomicAdd(&mult[ent >> 16], 1u);
-                }
-            }
-        } else {
+        } else if (kind == p2::OP_EQ) {
             if (x[i] == UNSET || y[i] == UNSET)
                 bad = 2;
-            else if (kind == p2::OP_EQ)
-                r = x[i] == y[i] ? 1 : 0;
-            else if (i == 0)  // an inverse hint is always alone in its macro: the Fermat inversion is compiled once, not KMAX times
-                r = x[i] == y[i] ? 0 : gl::inv(gl::sub(x[i], y[i]));
             else
-                bad = 2;
+                r = x[i] == y[i] ? 1 : 0;
+        } else {
+            bad = 2;  // no other kind is ever scheduled into a chain
         }
         after[i] = cur[i];
         if (!bad) {
@@ -856,9 +839,9 @@ __device__ __forceinline__ int witness_exec_macro(const WitnessArgs& a, u64* val
     return worst;
 }
 
-// One workgroup generates one witness.  The program is scheduled (witness_schedule.h) into levels of MACROS: a macro is a short
-// straight-line run of ops that one thread executes in order, the macros of a level are independent, and a workgroup barrier
-// separates the levels.  The descriptors are shared by all proofs (L2-resident).
+// One workgroup generates one witness.  The program is scheduled (witness_schedule.h) into levels; a level holds a few CHAINS
+// (the contracted critical path: each run in order by one thread) and many independent SINGLE ops, WITNESS_MLP of which a
+// thread keeps in flight together; a workgroup barrier separates the levels.  The descriptors are shared by all proofs.
 template <bool HAS_POSEIDON>
 __global__ __launch_bounds__(512) void k_witness(WitnessArgs a) {
     __shared__ int s_status;
@@ -886,35 +869,104 @@ __global__ __launch_bounds__(512) void k_witness(WitnessArgs a) {
         if (bad) atomicMax(&s_status, 3);
     }
     __syncthreads();
-    // Neither the macro bounds nor the op descriptors depend on witness values, so each thread fetches the bounds and the first
-    // descriptor of its first macro of level lv + 1 before it starts on level lv: on deep circuits (10^3..10^4 levels,
-    // descriptors streaming from HBM) that latency is otherwise the longest link of the per-level dependency chain.
+    // The op descriptors do not depend on witness values, so each thread fetches its first single-op descriptor of level
+    // lv + 1 before it starts on level lv: on deep circuits (10^3..10^4 levels, descriptors streaming from HBM) the descriptor
+    // latency is otherwise the longest link of the per-level dependency chain.
     p2::Op nxt;
-    u32 nxt_ob = 0, nxt_oe = 0;
-    u32 nbeg = a.level_offsets[0], nend = a.num_levels ? a.level_offsets[1] : nbeg;
-    if (nbeg + threadIdx.x < nend) {
-        nxt_ob = a.macro_offsets[nbeg + threadIdx.x];
-        nxt_oe = a.macro_offsets[nbeg + threadIdx.x + 1];
-        nxt = a.ops[nxt_ob];
+    bool have_nxt = false;
+    p2::WLevel NL = a.levels[0];
+    if (NL.single_begin + threadIdx.x < NL.single_end) {
+        nxt = a.ops[NL.single_begin + threadIdx.x];
+        have_nxt = true;
     }
     for (u32 lv = 0; lv < a.num_levels; lv++) {
-        const u32 beg = nbeg, end = nend;
+        const p2::WLevel L = NL;
         const p2::Op first = nxt;
-        const u32 first_ob = nxt_ob, first_oe = nxt_oe;
+        const bool have_first = have_nxt;
+        have_nxt = false;
         if (lv + 1 < a.num_levels) {
-            nbeg = end;
-            nend = a.level_offsets[lv + 2];
-            if (nbeg + threadIdx.x < nend) {
-                nxt_ob = a.macro_offsets[nbeg + threadIdx.x];
-                nxt_oe = a.macro_offsets[nbeg + threadIdx.x + 1];
-                nxt = a.ops[nxt_ob];
+            NL = a.levels[lv + 1];
+            if (NL.single_begin + threadIdx.x < NL.single_end) {
+                nxt = a.ops[NL.single_begin + threadIdx.x];
+                have_nxt = true;
             }
         }
         int worst = 0;
-        for (u32 m = beg + threadIdx.x; m < end; m += blockDim.x) {
-            const bool pre = m == beg + threadIdx.x;
-            const u32 ob = pre ? first_ob : a.macro_offsets[m], oe = pre ? first_oe : a.macro_offsets[m + 1];
-            worst = max(worst, witness_exec_macro<HAS_POSEIDON>(a, val, mult, proof, ob, min(oe - ob, (u32)WITNESS_KMAX), first, pre));
+        // the contracted critical path first: it is what the next level waits for
+        for (u32 ci = threadIdx.x; ci < L.chain_count; ci += blockDim.x) {
+            const p2::WChain ch = a.chains[L.chain_begin + ci];
+            worst = max(worst, witness_exec_chain(a, val, ch.start, min(ch.count, (u32)WITNESS_KMAX)));
+        }
+        // stages of a single op: descriptor, then every operand together with the present value of the output slot (it does
+        // not depend on the operands), then the table entry of a lookup; WITNESS_MLP ops go through them side by side
+        for (u32 k0 = L.single_begin + threadIdx.x; k0 < L.single_end; k0 += WITNESS_MLP * blockDim.x) {
+            p2::Op o[WITNESS_MLP];
+            bool act[WITNESS_MLP];
+#pragma unroll
+            for (int u = 0; u < WITNESS_MLP; u++) {
+                const u32 k = k0 + u * blockDim.x;
+                act[u] = k < L.single_end;
+                if (act[u]) o[u] = (u == 0 && have_first && k0 == L.single_begin + threadIdx.x) ? first : a.ops[k];
+            }
+            u64 x[WITNESS_MLP], y[WITNESS_MLP], z[WITNESS_MLP], cur[WITNESS_MLP], ent[WITNESS_MLP];
+#pragma unroll
+            for (int u = 0; u < WITNESS_MLP; u++) {
+                x[u] = y[u] = z[u] = cur[u] = 0;
+                if (!act[u] || o[u].kind == p2::OP_POSEIDON) continue;
+                const u32 kind = o[u].kind;
+                cur[u] = val[o[u].out];
+                if (kind != p2::OP_CONST) x[u] = val[o[u].a];
+                if (kind == p2::OP_ARITH || kind == p2::OP_EQ || kind == p2::OP_EQINV) y[u] = val[o[u].b];
+                if (kind == p2::OP_ARITH) z[u] = val[o[u].c];
+            }
+#pragma unroll
+            for (int u = 0; u < WITNESS_MLP; u++) {
+                ent[u] = ~0ull;  // (flat entry index << 16) | output, or ~0
+                if (act[u] && o[u].kind == p2::OP_LOOKUP && x[u] < 65536) ent[u] = a.lut_ent[(size_t)o[u].aux * 65536 + x[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < WITNESS_MLP; u++) {
+                if (!act[u]) continue;
+                const u32 kind = o[u].kind;
+                u64 r = 0;
+                int bad = 0;
+                if (kind == p2::OP_POSEIDON) {
+                    if (HAS_POSEIDON) bad = witness_poseidon_op(a, val, proof, o[u]);
+                    if (bad) worst = max(worst, bad == 1 ? 3 : 2);
+                    continue;
+                }
+                if (kind == p2::OP_ARITH) {
+                    if (x[u] == UNSET || y[u] == UNSET || z[u] == UNSET)
+                        bad = 2;
+                    else
+                        r = gl::add(gl::mul(gl::mul(x[u], y[u]), o[u].k0), gl::mul(z[u], o[u].k1));
+                } else if (kind == p2::OP_CONST) {
+                    r = o[u].k0;
+                } else if (kind == p2::OP_LOOKUP) {
+                    if (x[u] == UNSET) {
+                        bad = 2;
+                    } else if (ent[u] == ~0ull) {  // not a 16-bit value, or not in the table
+                        bad = 1;
+                    } else {
+                        r = ent[u] & 0xFFFF;
+                        atomicAdd(&mult[ent[u] >> 16], 1u);
+                    }
+                } else {
+                    if (x[u] == UNSET || y[u] == UNSET)
+                        bad = 2;
+                    else if (kind == p2::OP_EQ)
+                        r = x[u] == y[u] ? 1 : 0;
+                    else
+                        r = x[u] == y[u] ? 0 : gl::inv(gl::sub(x[u], y[u]));
+                }
+                if (!bad) {
+                    if (cur[u] == UNSET)
+                        val[o[u].out] = r;
+                    else if (cur[u] != r)
+                        bad = 1;
+                }
+                if (bad) worst = max(worst, bad == 1 ? 3 : 2);  // conflict (1) outranks missing input (2); remapped below
+            }
         }
         if (worst) atomicMax(&s_status, worst);
         __syncthreads();

@@ -3,6 +3,7 @@
 // stream per circuit handle; no host synchronisation between stages (Fiat-Shamir runs in a device kernel).
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <cstring>
 
 #include <algorithm>
 #include <map>
@@ -13,7 +14,6 @@
 
 #include "capi_common.h"
 #include "os_random.h"
-#include "witness_schedule.h"
 #include "kernels.h"
 #include "kernels2.h"
 
@@ -73,8 +73,9 @@ struct p2_circuit {
     std::vector<u32> arities;
     // ---- static device data
     Op* d_ops = nullptr;
-    u32 *d_level_offsets = nullptr, *d_macro_offsets = nullptr;
-    u32 witness_levels = 0, witness_macros = 0;
+    WLevel* d_wlevels = nullptr;
+    WChain* d_wchains = nullptr;
+    u32 witness_levels = 0;
     int32_t* d_wire_slot = nullptr;
     u64* d_lut_ent = nullptr;
     u32 *d_lut_pairs = nullptr, *d_lut_offsets = nullptr, *d_num_lookups = nullptr;
@@ -116,6 +117,7 @@ struct p2_circuit {
     size_t opt_chunk = 128, opt_streams = 2;
     std::map<const u64*, u64*> pass1_out_tw;  // two-pass NTT: output-twiddle table per full twiddle table (ensure_pass1_table)
     bool opt_merkle_top = true;               // P2AES_MERKLE_TOP=0: every level its own launch (A/B measurements)
+    bool opt_pass1_noswizzle = false;         // P2AES_PASS1_NOSWIZZLE: pass-1 workgroups in launch order (A/B measurements)
     bool opt_pass1_radix2 = false;            // P2AES_PASS1_RADIX2: the round-2 pass-1 kernel (A/B measurements)
     u32 opt_witness_fuse = 8;  // most ops per witness macro (P2AES_WITNESS_FUSE at load; 1 = one op per thread per level)
     bool opt_debug_timing = false;
@@ -220,6 +222,7 @@ static int ntt_big(p2_circuit* C, const char* name, const u64* in, u64* out, con
     auto it = C->pass1_out_tw.find(tw_full);
     if (it == C->pass1_out_tw.end()) return set_error("internal: no pass-1 twiddle table for this transform"), P2_ERR_INVALID;
     a.out_tw = it->second;
+    a.xcd_swizzle = (cosets > 1 && !in_coset_blocks && !C->opt_pass1_noswizzle) ? 1 : 0;  // only where workgroups share their input
     if (C->opt_pass1_radix2)
         LAUNCH(C, name, k_ntt_pass1, dim3(tiles * cols * cosets, batch), dim3(256), (size_t)8 << 12, a);
     else
@@ -346,14 +349,13 @@ static int circuit_setup(p2_circuit* C) {
     if (c.cfg.num_challenges > 2) return set_error("k_perm_chunks handles at most two challenges"), P2_ERR_INVALID;
     if (c.num_partial_products() + 1 > PERM_MAX_CHUNKS) return set_error("more partial-product chunks than k_perm_scan holds in registers"), P2_ERR_INVALID;
     {
-        // the witness program, rescheduled for the device: levels of macros (witness_schedule.h)
+        // the witness program, rescheduled for the device: contracted critical chains + single ops per level (witness_schedule.h)
         WitnessSchedule ws = schedule_witness(c, std::min<u32>(C->opt_witness_fuse, WITNESS_KMAX));
-        if (ws.max_macro > (u32)WITNESS_KMAX) return set_error("internal: witness macro larger than the kernel is unrolled for"), P2_ERR_INVALID;
-        C->witness_levels = (u32)ws.level_offsets.size() - 1;
-        C->witness_macros = (u32)ws.macro_offsets.size() - 1;
+        if (ws.max_chain > (u32)WITNESS_KMAX) return set_error("internal: witness chain longer than the kernel is unrolled for"), P2_ERR_INVALID;
+        C->witness_levels = (u32)ws.levels.size();
         if (upload(C, &C->d_ops, ws.ops.data(), ws.ops.size())) return P2_ERR_HIP;
-        if (upload(C, &C->d_macro_offsets, ws.macro_offsets.data(), ws.macro_offsets.size())) return P2_ERR_HIP;
-        if (upload(C, &C->d_level_offsets, ws.level_offsets.data(), ws.level_offsets.size())) return P2_ERR_HIP;
+        if (upload(C, &C->d_wlevels, ws.levels.data(), ws.levels.size())) return P2_ERR_HIP;
+        if (upload(C, &C->d_wchains, ws.chains.data(), ws.chains.size())) return P2_ERR_HIP;
     }
     if (upload(C, &C->d_wire_slot, c.wire_slot.data(), c.wire_slot.size())) return P2_ERR_HIP;
     {
@@ -671,8 +673,8 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
     {
         WitnessArgs a{};
         a.ops = C->d_ops;
-        a.macro_offsets = C->d_macro_offsets;
-        a.level_offsets = C->d_level_offsets;
+        a.levels = C->d_wlevels;
+        a.chains = C->d_wchains;
         a.num_levels = C->witness_levels;
         a.num_slots = c.num_slots;
         a.n_inputs = n_inputs;
@@ -1042,11 +1044,28 @@ struct StagingLease {
     }
     ~StagingLease() {
         if (!S) return;
+        // every path out of p2_prove_batch, the error returns after an async copy included: nothing may still be reading or
+        // writing these buffers when the next caller leases them (a no-op on the success path, which has synchronised already)
+        if (S->stream) (void)hipStreamSynchronize(S->stream);
         std::lock_guard<std::mutex> lock(C->staging_mu);
         C->staging_free.push_back(S);
     }
 };
 
+// Every entry point that allocates (std::vector, std::map, std::thread) runs behind this guard: an exception becomes
+// P2_ERR_* + p2_last_error(), never std::terminate -- also on the worker threads of p2_prove_batch_multi.
+template <class F>
+static int guarded_rc(F&& f) {
+    try {
+        return f();
+    } catch (std::bad_alloc&) {
+        return set_error("out of host memory"), P2_ERR_HIP;
+    } catch (std::exception& e) {
+        return set_error(e.what()), P2_ERR_INVALID;
+    } catch (...) {
+        return set_error("unknown exception"), P2_ERR_INVALID;
+    }
+}
 extern "C" {
 
 int p2_gpu_device_count(void) {
@@ -1087,6 +1106,7 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
         if (const char* e = getenv("P2AES_CHUNK")) C->opt_chunk = (size_t)std::max(1, atoi(e));
         if (const char* e = getenv("P2AES_STREAMS")) C->opt_streams = (size_t)std::min(8, std::max(1, atoi(e)));
         C->opt_pass1_radix2 = getenv("P2AES_PASS1_RADIX2") != nullptr;
+        C->opt_pass1_noswizzle = getenv("P2AES_PASS1_NOSWIZZLE") != nullptr;
         if (const char* e = getenv("P2AES_MERKLE_TOP")) C->opt_merkle_top = atoi(e) != 0;
         if (const char* e = getenv("P2AES_WITNESS_FUSE")) C->opt_witness_fuse = (u32)std::min(1024, std::max(1, atoi(e)));
         C->opt_debug_timing = getenv("P2AES_DEBUG_TIMING") != nullptr;
@@ -1165,7 +1185,15 @@ int p2_circuit_verifier_data(const p2_circuit* C, uint64_t* out, size_t cap, siz
 }
 size_t p2_circuit_proof_bytes(const p2_circuit* C) { return C->pbytes; }
 int p2_circuit_set_zk_key(p2_circuit* C, const uint64_t key[4]) {
+    // TEST ONLY, and refused unless the process opted in: a fixed key is not secret, and a (key, proof index) pair that is used
+    // for two different witnesses breaks zero-knowledge.
+    const char* allow = getenv("P2AES_ALLOW_FIXED_ZK_KEY");
+    if (!allow || strcmp(allow, "1") != 0)
+        return set_error("p2_circuit_set_zk_key is a test hook: set P2AES_ALLOW_FIXED_ZK_KEY=1 to fix the blinding key (never in production)"), P2_ERR_INVALID;
     std::lock_guard<std::mutex> lock(C->mu);
+    bool same = true;
+    for (int i = 0; i < 4; i++) same = same && C->zk_key.k[i] == key[i] % gl::P;
+    if (same) return P2_OK;  // the proof counter keeps running: setting the key a handle already holds never replays an index
     for (int i = 0; i < 4; i++) C->zk_key.k[i] = key[i] % gl::P;
     C->zk_counter = 0;
     return P2_OK;
@@ -1201,8 +1229,14 @@ static int setup_polyrefs(p2_circuit* C) {
     return upload(C, &C->cur->d_polyrefs, v.data(), v.size());
 }
 
+static int prove_batch_device_impl(p2_circuit* C, size_t batch, const p2_target* targets, size_t n_targets, const uint64_t* d_values, uint8_t* d_proofs, int* d_status,
+                                   void* stream);
 int p2_prove_batch_device(p2_circuit* C, size_t batch, const p2_target* targets, size_t n_targets, const uint64_t* d_values, uint8_t* d_proofs, int* d_status,
                           void* stream) {
+    return guarded_rc([&] { return prove_batch_device_impl(C, batch, targets, n_targets, d_values, d_proofs, d_status, stream); });
+}
+static int prove_batch_device_impl(p2_circuit* C, size_t batch, const p2_target* targets, size_t n_targets, const uint64_t* d_values, uint8_t* d_proofs, int* d_status,
+                                   void* stream) {
     std::lock_guard<std::mutex> lock(C->mu);
     hipStream_t caller = (hipStream_t)stream;
     HIPCHECK(hipSetDevice(C->device));
@@ -1288,7 +1322,11 @@ int p2_circuit_synchronize(p2_circuit* C) {
     return P2_OK;
 }
 
+static int prove_batch_impl(p2_circuit* C, size_t batch, const p2_assignment* inputs, uint8_t* proofs, int* status);
 int p2_prove_batch(p2_circuit* C, size_t batch, const p2_assignment* inputs, uint8_t* proofs, int* status) {
+    return guarded_rc([&] { return prove_batch_impl(C, batch, inputs, proofs, status); });
+}
+static int prove_batch_impl(p2_circuit* C, size_t batch, const p2_assignment* inputs, uint8_t* proofs, int* status) {
     if (batch == 0) return P2_OK;
     HIPCHECK(hipSetDevice(C->device));
     // Fast path: every PartialWitness assigns the same target list in the same order.  Otherwise the batch is put on
@@ -1338,10 +1376,7 @@ int p2_prove_batch(p2_circuit* C, size_t batch, const p2_assignment* inputs, uin
     // one stream carries upload -> prove -> download; p2_prove_batch_device orders the proving streams with it
     HIPCHECK(hipMemcpyAsync(S->d_vals, hv, nvals * 8, hipMemcpyHostToDevice, S->stream));
     int rc = p2_prove_batch_device(C, batch, targets, nt, S->d_vals, S->d_proofs, S->d_stat, (void*)S->stream);
-    if (rc != P2_OK) {
-        (void)hipStreamSynchronize(S->stream);
-        return rc;
-    }
+    if (rc != P2_OK) return rc;  // (the lease drains S->stream on every way out)
     HIPCHECK(hipMemcpyAsync(S->h_proofs, S->d_proofs, batch * C->pbytes, hipMemcpyDeviceToHost, S->stream));
     HIPCHECK(hipMemcpyAsync(S->h_stat, S->d_stat, batch * sizeof(int), hipMemcpyDeviceToHost, S->stream));
     double t_c = now();
@@ -1359,7 +1394,13 @@ int p2_prove_batch(p2_circuit* C, size_t batch, const p2_assignment* inputs, uin
 }
 
 // In-process multi-device form of p2_prove_batch: contiguous balanced ranges of the batch, one host thread per handle.
+// zk circuits: every handle blinds with ITS OWN key (drawn from the OS at load) and its own proof counter; handles that were
+// given one fixed key by the test hook would blind different witnesses with the same (key, index) values.
+static int prove_batch_multi_impl(p2_circuit* const* handles, size_t n_handles, size_t batch, const p2_assignment* inputs, uint8_t* proofs, int* status);
 int p2_prove_batch_multi(p2_circuit* const* handles, size_t n_handles, size_t batch, const p2_assignment* inputs, uint8_t* proofs, int* status) {
+    return guarded_rc([&] { return prove_batch_multi_impl(handles, n_handles, batch, inputs, proofs, status); });
+}
+static int prove_batch_multi_impl(p2_circuit* const* handles, size_t n_handles, size_t batch, const p2_assignment* inputs, uint8_t* proofs, int* status) {
     if (n_handles == 0 || !handles) return set_error("p2_prove_batch_multi needs at least one handle"), P2_ERR_INVALID;
     for (size_t h = 0; h < n_handles; h++)
         if (!handles[h] || handles[h]->pbytes != handles[0]->pbytes || handles[h]->verifier_data != handles[0]->verifier_data)

@@ -1,24 +1,26 @@
 // Device-side schedule of the witness program (host code, run once per circuit at p2_circuit_load).
 //
-// The compiled circuit carries its witness program as ops sorted into dependency levels (builder.h): level l holds every op
-// whose inputs are ready after level l - 1, and k_witness runs one level per workgroup barrier.  That is the right shape for a
-// wide circuit (AES-GCM 1 KiB: 170 k ops in 381 levels), and the wrong one for a deep one: AesGcm128Target<65536> is 10.7 M
-// ops in 16.5 k levels, almost all of them the carry chain of inc32 (aes-gcm/src/circuit_gcm.rs:350-368: add, is_equal, mul
-// and a two-op select per counter byte, block after block), and a level costs its barrier and its dependent memory round
-// trips -- about 4 us -- however few ops it holds (round 2: 69 ms per 8-proof chunk, 8 workgroups on a 256-CU chip).
+// The compiled circuit carries its witness program as ops sorted into dependency levels (builder.h), and k_witness runs one
+// level per workgroup barrier, one workgroup per proof.  Two things bound that kernel, and they are different things:
+//   * DEPTH: a level costs its chain of dependent memory round trips plus the barrier -- about 4 us -- however few ops it
+//     holds.  AesGcm128Target<65536> is 16.5 k levels deep, almost all of it the carry chain of inc32
+//     (aes-gcm/src/circuit_gcm.rs:350-368: add, is_equal, mul and a two-op select per counter byte, block after block);
+//   * WIDTH: a thread works on one op per round trip, so 10.7 M ops on 512 threads are 20.8 k trips of ~3.3 us.
+// Round 2's kernel sat on both at once (69 ms per 8-proof chunk either way), which is why neither wider workgroups nor more
+// ops in flight per thread alone moved it.
 //
-// So the levels are rebuilt here around MACROS: a macro is a short straight-line run of ops that ONE thread executes in
-// order, and a level is a set of macros with no dependencies among them.  An op joins the macro of its latest producer when
-// every input that becomes ready that late comes from that one macro (its other inputs are older) and the macro is not full;
-// otherwise it starts a macro of its own one level later.  Chains contract by the cap K (one barrier per K chain links), wide
-// levels lose nothing they need (there are far more macros than threads), and the values computed are the same, op for op:
-// every op still reads its operands from, and writes its result to, the slot array; inside a macro the reads follow the
-// writes of the same thread in program order, across macros the workgroup barrier of the level orders them.
+// The schedule built here takes the depth apart.  Only 0.6 % of the ops are on or next to the critical path: the counter
+// chain.  Those -- ops with no slack whose kind needs no table lookup -- are fused into CHAINS: short straight-line runs (at
+// most `max_chain` ops) that ONE thread executes in order, reading every operand the chain does not produce itself in a
+// single batch of loads and forwarding the rest through registers (k_witness, witness_exec_chain).  Everything else stays a
+// SINGLE op, scheduled as early as its inputs allow against the contracted chain.  64 KiB circuit: 12.4 k levels unfused,
+// 2.6 k with chains of 8, with 63 k of 10.7 M ops fused; the singles of a level are then wide enough (4 k on average) for every
+// thread to keep several in flight.
 //
 // Semantics kept from the builder's levelisation: a slot is produced by its FIRST producer in program order; any later
 // producer of the same slot (two computed values tied by `connect`) depends on it and only checks equality; the inverse hints
-// (OP_EQINV) are held back until everything else is scheduled.  PoseidonGenerator ops (a whole gate row per thread) are never
-// fused.
+// (OP_EQINV) are held back until everything else is scheduled.  Values computed, checks made and statuses reported are the
+// same, op for op.
 #pragma once
 #include <algorithm>
 #include <stdexcept>
@@ -28,109 +30,184 @@
 
 namespace p2 {
 
+struct WLevel {
+    u32 chain_begin, chain_count;    // chains [chain_begin, chain_begin + chain_count) of WitnessSchedule::chains
+    u32 single_begin, single_end;    // single ops ops[single_begin, single_end)
+};
+struct WChain {
+    u32 start, count;                // ops[start, start + count), executed in order by one thread
+};
 struct WitnessSchedule {
-    std::vector<Op> ops;              // reordered: level by level, macro by macro
-    std::vector<u32> macro_offsets;   // macro m = ops[macro_offsets[m], macro_offsets[m + 1])
-    std::vector<u32> level_offsets;   // level l = macros [level_offsets[l], level_offsets[l + 1])
-    u32 max_macro = 0;
+    std::vector<Op> ops;             // reordered: level by level; inside a level the chains' ops, then the singles
+    std::vector<WLevel> levels;
+    std::vector<WChain> chains;
+    u32 max_chain = 0;
+    size_t fused_ops = 0;
 };
 
-// K = most ops per macro (1 = one op per thread per level, the plain levelisation)
-inline WitnessSchedule schedule_witness(const Circuit& c, u32 K) {
+// max_chain = most ops per chain (1 = no fusion: the plain levelisation); slack = how far from the critical path (in levels
+// of the unfused schedule) an op may be and still be fused
+inline WitnessSchedule schedule_witness(const Circuit& c, u32 max_chain, u32 slack = 0) {
     const size_t M = c.ops.size(), n = (size_t)1 << c.degree_bits;
     const u32 R = c.cfg.num_routed_wires;
     WitnessSchedule s;
     if (M == 0) {
-        s.macro_offsets = {0};
-        s.level_offsets = {0, 0};
+        s.levels.push_back(WLevel{0, 0, 0, 0});
         return s;
     }
-    K = std::max<u32>(K, 1);
-    std::vector<int32_t> slot_macro(c.num_slots, -1);  // macro of the slot's first producer
-    std::vector<u32> macro_level, macro_size, macro_head, macro_tail;
-    std::vector<uint8_t> macro_closed;
-    std::vector<u32> next_op(M, ~0u);
-    macro_level.reserve(M / 2);
-    u32 max_level = 0, floor_level = 0;
-    bool seen_inv = false;
+    max_chain = std::max<u32>(max_chain, 1);
     auto wslot = [&](u32 row, u32 col) -> u32 { return (u32)c.wire_slot[(size_t)col * n + row]; };
-    u32 deps[96];
-    for (size_t i = 0; i < M; i++) {
-        const Op& o = c.ops[i];
-        int nd = 0, first_out = 0;
+    // operands, then outputs, of an op
+    auto slots_of = [&](const Op& o, u32* d, int& first_out) {
+        int nd = 0;
         if (o.kind == OP_ARITH) {
-            deps[nd++] = o.a, deps[nd++] = o.b, deps[nd++] = o.c;
+            d[nd++] = o.a, d[nd++] = o.b, d[nd++] = o.c;
         } else if (o.kind == OP_LOOKUP) {
-            deps[nd++] = o.a;
+            d[nd++] = o.a;
         } else if (o.kind == OP_EQ || o.kind == OP_EQINV) {
-            deps[nd++] = o.a, deps[nd++] = o.b;
+            d[nd++] = o.a, d[nd++] = o.b;
         } else if (o.kind == OP_POSEIDON) {
-            for (u32 k = 0; k < 12; k++) deps[nd++] = wslot(o.a, PG_IN + k);
-            deps[nd++] = wslot(o.a, PG_SWAP);
+            for (u32 k = 0; k < 12; k++) d[nd++] = wslot(o.a, PG_IN + k);
+            d[nd++] = wslot(o.a, PG_SWAP);
         }
         first_out = nd;
         if (o.kind == OP_POSEIDON) {
             for (u32 col = PG_OUT; col < R; col++)
-                if (col != PG_SWAP) deps[nd++] = wslot(o.a, col);
+                if (col != PG_SWAP) d[nd++] = wslot(o.a, col);
         } else {
-            deps[nd++] = o.out;
+            d[nd++] = o.out;
         }
-        // latest producer level among the inputs and the (possibly already produced) outputs
+        for (int j = 0; j < nd; j++)
+            if (d[j] >= c.num_slots) throw std::runtime_error("witness op refers to a slot outside the circuit");
+        return nd;
+    };
+    u32 d[96];
+    int fo;
+    // ---- pass A: as-soon-as-possible levels of the unfused program, then as-late-as-possible ones: slack = alap - asap
+    std::vector<int32_t> producer(c.num_slots, -1);  // first producer (op index) of a slot
+    std::vector<u32> asap(M), alap;
+    u32 depth = 0, floor_level = 0;
+    bool seen_inv = false;
+    for (size_t i = 0; i < M; i++) {
+        const int nd = slots_of(c.ops[i], d, fo);
+        int lv = -1;
+        for (int j = 0; j < nd; j++)
+            if (producer[d[j]] >= 0) lv = std::max(lv, (int)asap[producer[d[j]]]);
+        if (c.ops[i].kind == OP_EQINV && !seen_inv) {
+            seen_inv = true;
+            floor_level = depth + 1;
+        }
+        u32 l = (u32)(lv + 1);
+        if (c.ops[i].kind == OP_EQINV) l = std::max(l, floor_level);
+        asap[i] = l;
+        if (!seen_inv) depth = std::max(depth, l);
+        for (int j = fo; j < nd; j++)
+            if (producer[d[j]] < 0) producer[d[j]] = (int32_t)i;
+    }
+    // `depth` = last level before the inverse hints; ops at or behind the hints (asap > depth) are never fused
+    alap.assign(M, depth);
+    if (max_chain > 1) {
+        for (size_t i = M; i-- > 0;) {
+            if (asap[i] > depth) {
+                alap[i] = asap[i];
+                continue;  // the deferred tail does not constrain what feeds it
+            }
+            const int nd = slots_of(c.ops[i], d, fo);
+            const u32 mine = alap[i];
+            for (int j = 0; j < nd; j++) {
+                const int32_t p = producer[d[j]];
+                if (p >= 0 && (size_t)p != i) alap[p] = std::min(alap[p], mine ? mine - 1 : 0);
+            }
+        }
+    }
+    // ---- pass B: levels again, with near-critical lookup-free ops joining the chain of their latest producer
+    std::vector<int32_t> slot_unit(c.num_slots, -1);  // unit (chain or single) of the slot's first producer
+    std::vector<u32> unit_level, unit_size, unit_head, unit_tail;
+    std::vector<uint8_t> unit_open;
+    std::vector<u32> next_op(M, ~0u);
+    unit_level.reserve(M);
+    u32 max_level = 0;
+    floor_level = 0;
+    seen_inv = false;
+    for (size_t i = 0; i < M; i++) {
+        const Op& o = c.ops[i];
+        const int nd = slots_of(o, d, fo);
         int lv = -1;
         int32_t from = -1;
-        bool single = true;
+        bool single_source = true;
         for (int j = 0; j < nd; j++) {
-            if (deps[j] >= c.num_slots) throw std::runtime_error("witness op refers to a slot outside the circuit");
-            const int32_t pm = slot_macro[deps[j]];
-            if (pm < 0) continue;
-            const int l = (int)macro_level[pm];
+            const int32_t pu = slot_unit[d[j]];
+            if (pu < 0) continue;
+            const int l = (int)unit_level[pu];
             if (l > lv) {
-                lv = l, from = pm, single = true;
-            } else if (l == lv && pm != from) {
-                single = false;
+                lv = l, from = pu, single_source = true;
+            } else if (l == lv && pu != from) {
+                single_source = false;
             }
         }
         if (o.kind == OP_EQINV && !seen_inv) {
             seen_inv = true;
             floor_level = max_level + 1;
         }
+        const bool chainable = (o.kind == OP_ARITH || o.kind == OP_CONST || o.kind == OP_EQ) && asap[i] <= depth && alap[i] - asap[i] <= slack;
         int32_t mine;
-        const bool fusable = o.kind != OP_EQINV && o.kind != OP_POSEIDON;
-        if (fusable && lv >= 0 && single && !macro_closed[from] && macro_size[from] < K) {
+        if (max_chain > 1 && chainable && lv >= 0 && single_source && unit_open[from] && unit_size[from] < max_chain) {
             mine = from;
-            next_op[macro_tail[from]] = (u32)i;
-            macro_tail[from] = (u32)i;
-            macro_size[from]++;
+            next_op[unit_tail[from]] = (u32)i;
+            unit_tail[from] = (u32)i;
+            unit_size[from]++;
+            s.fused_ops++;
         } else {
             u32 l = (u32)(lv + 1);
             if (o.kind == OP_EQINV) l = std::max(l, floor_level);
-            mine = (int32_t)macro_level.size();
-            macro_level.push_back(l);
-            macro_size.push_back(1);
-            macro_head.push_back((u32)i);
-            macro_tail.push_back((u32)i);
-            macro_closed.push_back(o.kind == OP_POSEIDON || o.kind == OP_EQINV);
+            mine = (int32_t)unit_level.size();
+            unit_level.push_back(l);
+            unit_size.push_back(1);
+            unit_head.push_back((u32)i);
+            unit_tail.push_back((u32)i);
+            unit_open.push_back(chainable);  // a chain starts at, and only holds, chainable ops
             max_level = std::max(max_level, l);
         }
-        for (int j = first_out; j < nd; j++)
-            if (slot_macro[deps[j]] < 0) slot_macro[deps[j]] = mine;
+        for (int j = fo; j < nd; j++)
+            if (slot_unit[d[j]] < 0) slot_unit[d[j]] = mine;
     }
-    const size_t NM = macro_level.size();
-    s.level_offsets.assign((size_t)max_level + 2, 0);
-    for (size_t m = 0; m < NM; m++) s.level_offsets[macro_level[m] + 1]++;
-    for (u32 l = 0; l <= max_level; l++) s.level_offsets[l + 1] += s.level_offsets[l];
-    std::vector<u32> cursor(s.level_offsets.begin(), s.level_offsets.end() - 1), order(NM);
-    for (size_t m = 0; m < NM; m++) order[cursor[macro_level[m]]++] = (u32)m;  // stable: macros keep their program order inside a level
-    s.ops.reserve(M);
-    s.macro_offsets.reserve(NM + 1);
-    for (size_t k = 0; k < NM; k++) {
-        const u32 m = order[k];
-        s.macro_offsets.push_back((u32)s.ops.size());
-        for (u32 i = macro_head[m]; i != ~0u; i = next_op[i]) s.ops.push_back(c.ops[i]);
-        s.max_macro = std::max(s.max_macro, macro_size[m]);
+    // ---- lay out: per level the chains (units of more than one op), then the singles, both in program order
+    const size_t NU = unit_level.size();
+    std::vector<u32> n_chain(max_level + 1, 0), n_chain_ops(max_level + 1, 0), n_single(max_level + 1, 0);
+    for (size_t u = 0; u < NU; u++) {
+        if (unit_size[u] > 1)
+            n_chain[unit_level[u]]++, n_chain_ops[unit_level[u]] += unit_size[u];
+        else
+            n_single[unit_level[u]]++;
     }
-    s.macro_offsets.push_back((u32)s.ops.size());
-    if (s.ops.size() != M) throw std::runtime_error("internal: witness schedule lost ops");
+    s.levels.resize((size_t)max_level + 1);
+    u32 op_cursor = 0, chain_cursor = 0;
+    std::vector<u32> chain_op_cur(max_level + 1), chain_cur(max_level + 1), single_cur(max_level + 1);
+    for (u32 l = 0; l <= max_level; l++) {
+        s.levels[l].chain_begin = chain_cursor;
+        s.levels[l].chain_count = n_chain[l];
+        chain_cur[l] = chain_cursor;
+        chain_op_cur[l] = op_cursor;
+        chain_cursor += n_chain[l];
+        op_cursor += n_chain_ops[l];
+        s.levels[l].single_begin = op_cursor;
+        single_cur[l] = op_cursor;
+        op_cursor += n_single[l];
+        s.levels[l].single_end = op_cursor;
+    }
+    if (op_cursor != M) throw std::runtime_error("internal: witness schedule lost ops");
+    s.ops.resize(M);
+    s.chains.resize(chain_cursor);
+    for (size_t u = 0; u < NU; u++) {
+        const u32 l = unit_level[u];
+        if (unit_size[u] > 1) {
+            s.chains[chain_cur[l]++] = WChain{chain_op_cur[l], unit_size[u]};
+            for (u32 i = unit_head[u]; i != ~0u; i = next_op[i]) s.ops[chain_op_cur[l]++] = c.ops[i];
+            s.max_chain = std::max(s.max_chain, unit_size[u]);
+        } else {
+            s.ops[single_cur[l]++] = c.ops[unit_head[u]];
+        }
+    }
     return s;
 }
 

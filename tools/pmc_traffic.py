@@ -4,7 +4,7 @@ per-launch HBM traffic JSON that bench.py reads (profiles/r01_traffic.json).
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
-    python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write <proofs per chunk> > profiles/r01_traffic.json
+    python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write <proofs per chunk> [--src-id gpurun_out/<tag>_srcid.json] [--git-head SHA] > profiles/<tag>_traffic.json
 
 Counters are KiB.  gfx950 correction (tools/microbench/traffic_calib.hip, profiles/r01_pmc_calibration_*.csv): a kernel
 streaming 2 GiB with 8 B/lane loads reports FETCH_SIZE = 1.0 GiB, so FETCH_SIZE is doubled; WRITE_SIZE is exact."""
@@ -29,9 +29,11 @@ def load(d, counter):
 
 def main():
     fd, wd, chunk = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from src_id import load_src_id
     fe, wr = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
     out = {"method": __doc__.split("\n\n")[1].strip() + "  Counters are KiB; FETCH_SIZE doubled (8 B/lane loads), WRITE_SIZE exact.",
-           "chunk": chunk, "per_launch_avg_bytes": {}}
+           "chunk": chunk, "source": load_src_id(sys.argv), "per_launch_avg_bytes": {}}
     for name in sorted(fe, key=lambda k: -sum(v for _, v in fe[k])):
         f, w = fe[name], wr.get(name, [])
         if len(f) != len(w):

@@ -3,7 +3,7 @@
 
     rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE \
         -d gpurun_out/pmc_valu_<tag> --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
-    python3 tools/pmc_valu.py gpurun_out/pmc_valu_<tag> > profiles/<tag>_valu.json
+    python3 tools/pmc_valu.py gpurun_out/pmc_valu_<tag> [--src-id gpurun_out/<tag>_srcid.json] [--git-head SHA] > profiles/<tag>_valu.json
 
 For every kernel (launches of one name and grid size are averaged; the largest grid of a name is reported):
     duration_ms     dispatch End - Start of the SAME pass (counter collection serialises kernels and slows them a little)
@@ -45,7 +45,9 @@ def main():
     for (name, grid), es in by.items():
         if name not in best or grid > best[name][0]:
             best[name] = (grid, es)
-    out = {"method": __doc__.strip().split("\n\n")[1], "kernels": {}}
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from src_id import load_src_id
+    out = {"method": __doc__.strip().split("\n\n")[1], "source": load_src_id(sys.argv), "kernels": {}}
     total = sum(e["dur"] for e in rows.values())
     for name, (grid, es) in sorted(best.items(), key=lambda kv: -sum(e["dur"] for e in kv[1][1])):
         n = len(es)
