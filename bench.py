@@ -269,7 +269,7 @@ def main():
     kernels = {}
     if rank == 0:
         lib.p2_circuit_set_timing(h, 1)
-        chunk = (B + 1) // 2  # the size of the chunks the timed steps ran (B proofs over two streams)
+        chunk = int(lib.p2_circuit_chunk_proofs(h)) or (B + 1) // 2  # the size of the chunks the timed steps ran (equal chunks, capped by free HBM)
         rc = lib.p2_prove_batch_device(h, chunk, tarr, nt, vals.data_ptr(), proofs.data_ptr(), status.data_ptr(), torch_stream)  # one chunk = one stream
         assert rc == 0
         sync()

@@ -211,6 +211,9 @@ typedef struct p2_circuit p2_circuit;
 p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device);
 void p2_circuit_free(p2_circuit*);
 int p2_circuit_verifier_data(const p2_circuit*, uint64_t* out, size_t cap, size_t* n_written);
+/* Proofs per chunk of the workspaces the handle holds now (0 before the first proof): a batch is cut into equal chunks of
+ * at most this many proofs, dealt round-robin to the proving streams; the size is the "chunk" option capped by free HBM. */
+size_t p2_circuit_chunk_proofs(p2_circuit*);
 /* zk circuits only.  Blinding values are the output of a Poseidon-based PRF under a 256-bit key (four field elements)
  * and a per-handle proof counter that advances with every proof attempted.  The key is drawn from the operating system's
  * CSPRNG at load time (upstream: OS randomness per proof) -- that is the production path and needs no call here.

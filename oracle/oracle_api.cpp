@@ -174,4 +174,8 @@ void orc_gcm_encrypt(const uint8_t* key, int nk, const uint8_t* iv, const uint8_
 }
 int orc_num_threads() { return omp_get_max_threads(); }
 void orc_set_num_threads(int t) { omp_set_num_threads(t); }
+// 1: every Poseidon permutation of the oracle runs in the sparse-partial-round form (oracle_poseidon_sparse.h); 0: the
+// textbook 30-round loop (the default, and what the parity tests use).  Process-wide.
+void orc_set_fast_hash(int on) { g_sparse_poseidon = on != 0; }
+void orc_poseidon_sparse(uint64_t* st) { poseidon_permute_sparse(st); }
 }

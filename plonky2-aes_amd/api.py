@@ -135,6 +135,7 @@ def lib():
         "p2_circuit_load": (vp, [C.c_char_p, sz, C.c_int]), "p2_circuit_free": (None, [vp]),
         "p2_circuit_verifier_data": (C.c_int, [vp, u64p, sz, C.POINTER(sz)]),
         "p2_circuit_proof_bytes": (sz, [vp]),
+        "p2_circuit_chunk_proofs": (sz, [vp]),
         "p2_prove_batch": (C.c_int, [vp, sz, C.POINTER(_Assignment), C.c_char_p, C.POINTER(C.c_int)]),
         "p2_prove_batch_device": (C.c_int, [vp, sz, u64p, sz, vp, vp, vp, vp]),
         "p2_circuit_synchronize": (C.c_int, [vp]),

@@ -121,8 +121,23 @@ __global__ __launch_bounds__(256) P2_HASH_WAVES void k_merkle_top(u64* __restric
     u64* base = dig + (size_t)blockIdx.y * batch_stride;
     u32 P = ((1u << bits) >> (first_level + 1)) / gridDim.x;  // parents of this workgroup at its first level (<= 256)
     for (u32 k = 0, l = first_level; k < num_levels; k++, l++, P >>= 1) {
-        if (threadIdx.x < P) {
-            const size_t off_c = 4 * (((size_t)2 << bits) - ((size_t)2 << (bits - l))), off_p = 4 * (((size_t)2 << bits) - ((size_t)2 << (bits - l - 1)));
+        const size_t off_c = 4 * (((size_t)2 << bits) - ((size_t)2 << (bits - l))), off_p = 4 * (((size_t)2 << bits) - ((size_t)2 << (bits - l - 1)));
+        if (P <= 32 && blockDim.x >= 64) {
+            // Few nodes left: what the level costs is ONE permutation's latency, so spread each permutation over a 16-lane group
+            // (glf::poseidon_coop, the Fiat-Shamir sponge's form: 4.3 k instructions per lane instead of 15.5 k).  The walk is
+            // only fused for small batches, where this kernel IS the critical path (single-proof latency).
+            const u32 g = threadIdx.x >> 4, i = threadIdx.x & 15;
+            for (u32 first = 0; first < P; first += blockDim.x >> 4) {
+                if (first + ((threadIdx.x >> 6) << 2) < P) {  // wave-uniform: this wave's four groups hold at least one live node
+                    const u32 idx = first + g;
+                    const bool live = idx < P;
+                    const size_t node = (size_t)blockIdx.x * P + (live ? idx : 0);
+                    u64 w = (live && i < 8) ? base[off_c + 8 * node + i] : 0;
+                    w = glf::poseidon_coop(w, i);
+                    if (live && i < 4) base[off_p + 4 * node + i] = w;
+                }
+            }
+        } else if (threadIdx.x < P) {
             const size_t idx = (size_t)blockIdx.x * P + threadIdx.x;
             u64 st[12];
             {

@@ -303,7 +303,14 @@ static int merkle_levels(p2_circuit* C, Tree& t, u32 batch) {
     const u32 cap_h = C->c.cfg.cap_height;
     if (t.bits <= cap_h) return 0;
     const u32 levels = t.bits - cap_h;                       // level l: 2^(bits-l-1) parents
-    const u32 fused = C->opt_merkle_top ? std::min<u32>(levels, 9) : 0;  // the last `fused` levels: parents per cap subtree 2^(fused-1) .. 1
+    // The last `fused` levels (parents per cap subtree 2^(fused-1) .. 1) run as ONE launch of a workgroup per cap node -- for
+    // SMALL batches only.  These levels are latency bound either way (a level is one permutation deep whatever its width), so
+    // what the fusion buys is launches: 54 -> 18 per chunk, 118 -> 70 for the whole pipeline.  For a full chunk it costs time:
+    // the waves of a fused walk stay resident for all its levels and slow each other down, where separately launched levels
+    // shrink to one wave per SIMD as they narrow (measured per 128-proof chunk: nine levels in 256-thread workgroups + 3.3 ms,
+    // seven levels in one wave + 1.3 ms against 21.1 ms).  Launch count does not matter there: the chip is busy throughout.
+    const u32 fused = (C->opt_merkle_top && batch <= 16) ? std::min<u32>(levels, 9) : 0;
+    const u32 top_threads = 256;
     const size_t leaves = (size_t)1 << t.bits;
     for (u32 l = 0; l < levels - fused; l++) {
         size_t parents = leaves >> (l + 1);
@@ -311,7 +318,7 @@ static int merkle_levels(p2_circuit* C, Tree& t, u32 batch) {
         size_t off_p = 4 * (((size_t)2 << t.bits) - ((size_t)2 << (t.bits - l - 1)));
         LAUNCH(C, "merkle_level", k_merkle_level, g1(parents, 256, batch), dim3(256), 0, t.dig + off_c, t.dig + off_p, parents, t.stride());
     }
-    if (fused) LAUNCH(C, "merkle_top", k_merkle_top, dim3(1u << cap_h, batch), dim3(256), 0, t.dig, t.stride(), t.bits, levels - fused, fused);
+    if (fused) LAUNCH(C, "merkle_top", k_merkle_top, dim3(1u << cap_h, batch), dim3(top_threads), 0, t.dig, t.stride(), t.bits, levels - fused, fused);
     return 0;
 }
 static int merkle_build(p2_circuit* C, const u64* data, u32 cols, u32 active, size_t col_stride, size_t batch_stride, Tree& t, u32 batch) {
@@ -1184,6 +1191,10 @@ int p2_circuit_verifier_data(const p2_circuit* C, uint64_t* out, size_t cap, siz
     return P2_OK;
 }
 size_t p2_circuit_proof_bytes(const p2_circuit* C) { return C->pbytes; }
+size_t p2_circuit_chunk_proofs(p2_circuit* C) {
+    std::lock_guard<std::mutex> lock(C->mu);
+    return C->chunk;
+}
 int p2_circuit_set_zk_key(p2_circuit* C, const uint64_t key[4]) {
     // TEST ONLY, and refused unless the process opted in: a fixed key is not secret, and a (key, proof index) pair that is used
     // for two different witnesses breaks zero-knowledge.
@@ -1259,7 +1270,8 @@ static int prove_batch_device_impl(p2_circuit* C, size_t batch, const p2_target*
     // workspaces (alloc_workspace); a smaller one runs in the existing ones.
     size_t want_chunk = C->opt_chunk, want_streams = C->opt_streams;
     {
-        // cap the chunk so that all workspaces fit in ~70% of the HBM that is free (plus what the workspaces hold now)
+        // cap the chunk so that all workspaces fit in ~80% of the HBM that is free (plus what the workspaces hold now); chunks of
+        // a batch are then made EQUAL (a 32-proof batch under a cap of 14 is 3 x 11, not 14 + 14 + 4)
         const Circuit& c = C->c;
         size_t n = C->n, N = C->N, zc = c.num_zs_cols(), qc = c.num_quotient_cols(), act = C->active_wires, NC = c.cfg.num_challenges;
         size_t words = c.num_slots + (act + zc) * 2 * n + qc * n + (act + zc + qc) * N + NC * (c.num_partial_products() + c.num_sldc_polys() + 2) * n +
@@ -1267,12 +1279,16 @@ static int prove_batch_device_impl(p2_circuit* C, size_t batch, const p2_target*
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             free_b += 8 * words * C->chunk * C->ws.size();
-            size_t fit = (size_t)(0.7 * (double)free_b) / (8 * words * want_streams);
+            size_t fit = (size_t)(0.8 * (double)free_b) / (8 * words * want_streams);
             want_chunk = std::max<size_t>(1, std::min(want_chunk, fit));
         }
     }
     size_t nstreams = std::min(want_streams, std::max<size_t>(batch, 1));
     size_t chunk = std::min(want_chunk, (std::max<size_t>(batch, 1) + nstreams - 1) / nstreams);
+    {
+        const size_t nchunks = (std::max<size_t>(batch, 1) + chunk - 1) / chunk;
+        chunk = (std::max<size_t>(batch, 1) + nchunks - 1) / nchunks;
+    }
     if (C->chunk >= chunk && C->ws.size() >= nstreams) chunk = C->chunk, nstreams = C->ws.size();
     if (alloc_workspace(C, chunk, (u32)n_targets, nstreams)) return P2_ERR_HIP;
     // Ordering with the caller: the proving streams wait for everything already enqueued on the caller's stream (its

@@ -51,6 +51,8 @@ def lib():
         L.orc_last_stage_seconds.argtypes = [C.POINTER(C.c_double)]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_fast_hash.argtypes = [C.c_int]
+        L.orc_poseidon_sparse.argtypes = [u64p]
         _lib = L
     return _lib
 

@@ -28,6 +28,32 @@ def test_poseidon_upstream_test_vector(orc):
     assert st[0] == 0x3C18A9786CB0B359 and st[1] == 0xC4055E3364A246C3 and st[11] == 0x1792B1C4342109D7
 
 
+def test_sparse_partial_rounds_are_the_same_permutation(orc, pkg):
+    """oracle/oracle_poseidon_sparse.h (the faster permutation bench.py's cpu_baseline leg switches on): derived at start-up from
+    the MDS matrix and the round constants, it must be the SAME function as the textbook 30-round loop -- upstream's all-zero
+    vector, extreme words, 2000 random states -- and a whole proof must come out byte-identical with it switched on."""
+    L, r = orc.lib(), random.Random(7)
+    z = (C.c_uint64 * 12)()
+    L.orc_poseidon_sparse(z)
+    assert z[0] == 0x3C18A9786CB0B359 and z[11] == 0x1792B1C4342109D7
+    states = [[0] * 12, [P - 1] * 12, [1] + [0] * 11, list(range(12))] + [[r.randrange(P) for _ in range(12)] for _ in range(2000)]
+    for st in states:
+        a, b = (C.c_uint64 * 12)(*st), (C.c_uint64 * 12)(*st)
+        L.orc_poseidon(a)
+        L.orc_poseidon_sparse(b)
+        assert list(a) == list(b)
+    import circuits
+    data, pws = circuits.gf_2_8_mul(pkg, [(0x57, 0x13, 0xFE)])
+    oc = orc.OracleCircuit(data.blob)
+    st, ref = oc.prove(pws[0].map)
+    try:
+        L.orc_set_fast_hash(1)
+        st2, fast = orc.OracleCircuit(data.blob).prove(pws[0].map)
+    finally:
+        L.orc_set_fast_hash(0)
+    assert st == 0 and st2 == 0 and fast == ref
+
+
 def test_poseidon_constants_rederive():
     # the committed .inc files are what tools/gen_poseidon_constants.py derives (ChaCha8 seed 0, rand-0.8 gen_range)
     import importlib.util

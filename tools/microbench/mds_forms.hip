@@ -8,7 +8,8 @@
 //           v_mad_u64_u32 by 2^8, 2^16, 2^24 and folded as in form 0
 //   form 2  byte planes + v_mfma_i32_4x4x4_16b_i8: the same planes as the B operand (a lane's own four words of one plane),
 //           the coefficient rows as the A operand (constant per lane mod 4), D = 4 output rows of the lane's OWN state:
-//           no cross-lane movement at all, 72 MFMAs per layer, the products leave the VALU entirely
+//           no cross-lane movement at all, 72 MFMAs per layer, the products leave the VALU entirely (the matrix cores take
+//           SIGNED bytes: the planes are offset by 128 with one XOR per dword and the accumulators start from 128 x row sum)
 //
 // Every form is checked against form 0 (canonicalised, 2^20 random states incl. all-ones words) before anything is timed.
 // Timing: in-kernel s_memtime / s_memrealtime around >= 20 ms of work, 256 CUs x W blocks of 256 threads (W = 4, 5 waves per
@@ -116,13 +117,19 @@ struct MfmaCoeffs {
 __device__ __forceinline__ void mds_mfma(u64* s, const unsigned long long* rc, const MfmaCoeffs& M) {
     u32 pl[8][3];
     byte_planes(s, pl);
+    // the matrix cores multiply SIGNED bytes: feed b - 128 (one XOR per packed dword) and start every accumulator from
+    // 128 * (sum of the row's coefficients) -- 256 for every row of the circulant, 264 for row 0 with its extra 8 s[0]
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) pl[p][q] ^= 0x80808080u;
     u64 res[12];
 #pragma unroll
     for (int g = 0; g < 3; g++) {
         v4i D[8];
 #pragma unroll
         for (int p = 0; p < 8; p++) {
-            v4i acc = {0, 0, 0, 0};
+            v4i acc = {g == 0 ? 128 * 264 : 128 * 256, 128 * 256, 128 * 256, 128 * 256};
             acc = __builtin_amdgcn_mfma_i32_4x4x4i8(M.a[g][0], (int)pl[p][0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_i32_4x4x4i8(M.a[g][1], (int)pl[p][1], acc, 0, 0, 0);
             D[p] = __builtin_amdgcn_mfma_i32_4x4x4i8(M.a[g][2], (int)pl[p][2], acc, 0, 0, 0);
