@@ -112,32 +112,25 @@ __global__ __launch_bounds__(256) P2_HASH_WAVES void k_merkle_level(const u64* _
     for (int k = 0; k < 4; k++) o[k] = st[k];
 }
 
-// The TOP of a tree in one launch: workgroup w owns the subtree under cap node w (16 per proof) from the level at which that
-// subtree has at most 256 parents -- up to nine levels, 256, 128, ... 1 parents -- with a workgroup barrier between levels
-// instead of a kernel boundary.  Those levels hold 2^13 .. 2^4 hashes per proof: launched one by one (round 2) each of them
-// costs a whole permutation's latency plus a launch for next to no work (13 launches per tree, 54 per chunk; now 5 and 18).
+// The TOP of a tree in two launches (small batches only, see merkle_levels): workgroup w owns the subtree under cap node w (16
+// per proof) from the level at which that subtree has at most 256 parents -- up to nine levels, 256, 128, ... 1 parents -- with a
+// workgroup barrier between levels instead of a kernel boundary.  Those levels hold 2^13 .. 2^4 hashes per proof: launched one
+// by one (round 2) each of them costs a whole permutation's latency plus a launch for next to no work.
+//   k_merkle_top       levels with more than 32 parents per subtree: one thread per node (glf::poseidon);
+//   k_merkle_top_coop  the narrow rest: what such a level costs is ONE permutation's latency, so every permutation is spread over
+//                      a 16-lane group (glf::poseidon_coop, the Fiat-Shamir sponge's form: 4.3 k instructions per lane instead of
+//                      15.5 k; 26 us instead of 71 us per level).
+// Two kernels, not two branches of one: with both forms of the permutation in one kernel the compiler ran out of SGPRs and
+// reloaded spilled round constants with v_readlane right in front of the asm blocks that read them -- a VALU write of an SGPR
+// followed at once by a VALU read, the hazard its recogniser cannot see inside inline asm (tests/isa_lint.py flagged it on the
+// CPU box before it ever ran).
 // dig = the tree's digest levels as merkle_build lays them out; level l's nodes start at 4 * (2^(bits+1) - 2^(bits-l+1)).
 __global__ __launch_bounds__(256) P2_HASH_WAVES void k_merkle_top(u64* __restrict__ dig, size_t batch_stride, u32 bits, u32 first_level, u32 num_levels) {
     u64* base = dig + (size_t)blockIdx.y * batch_stride;
     u32 P = ((1u << bits) >> (first_level + 1)) / gridDim.x;  // parents of this workgroup at its first level (<= 256)
     for (u32 k = 0, l = first_level; k < num_levels; k++, l++, P >>= 1) {
-        const size_t off_c = 4 * (((size_t)2 << bits) - ((size_t)2 << (bits - l))), off_p = 4 * (((size_t)2 << bits) - ((size_t)2 << (bits - l - 1)));
-        if (P <= 32 && blockDim.x >= 64) {
-            // Few nodes left: what the level costs is ONE permutation's latency, so spread each permutation over a 16-lane group
-            // (glf::poseidon_coop, the Fiat-Shamir sponge's form: 4.3 k instructions per lane instead of 15.5 k).  The walk is
-            // only fused for small batches, where this kernel IS the critical path (single-proof latency).
-            const u32 g = threadIdx.x >> 4, i = threadIdx.x & 15;
-            for (u32 first = 0; first < P; first += blockDim.x >> 4) {
-                if (first + ((threadIdx.x >> 6) << 2) < P) {  // wave-uniform: this wave's four groups hold at least one live node
-                    const u32 idx = first + g;
-                    const bool live = idx < P;
-                    const size_t node = (size_t)blockIdx.x * P + (live ? idx : 0);
-                    u64 w = (live && i < 8) ? base[off_c + 8 * node + i] : 0;
-                    w = glf::poseidon_coop(w, i);
-                    if (live && i < 4) base[off_p + 4 * node + i] = w;
-                }
-            }
-        } else if (threadIdx.x < P) {
+        if (threadIdx.x < P) {
+            const size_t off_c = 4 * (((size_t)2 << bits) - ((size_t)2 << (bits - l))), off_p = 4 * (((size_t)2 << bits) - ((size_t)2 << (bits - l - 1)));
             const size_t idx = (size_t)blockIdx.x * P + threadIdx.x;
             u64 st[12];
             {
@@ -157,6 +150,25 @@ __global__ __launch_bounds__(256) P2_HASH_WAVES void k_merkle_top(u64* __restric
             for (int q = 0; q < 4; q++) o[q] = st[q];
         }
         __syncthreads();  // the parents just written are the next level's children (same workgroup: workgroup-scope ordering is enough)
+    }
+}
+__global__ __launch_bounds__(256) void k_merkle_top_coop(u64* __restrict__ dig, size_t batch_stride, u32 bits, u32 first_level, u32 num_levels) {
+    u64* base = dig + (size_t)blockIdx.y * batch_stride;
+    u32 P = ((1u << bits) >> (first_level + 1)) / gridDim.x;  // parents of this workgroup at its first level (<= 32 by the launch)
+    const u32 g = threadIdx.x >> 4, i = threadIdx.x & 15;
+    for (u32 k = 0, l = first_level; k < num_levels; k++, l++, P >>= 1) {
+        const size_t off_c = 4 * (((size_t)2 << bits) - ((size_t)2 << (bits - l))), off_p = 4 * (((size_t)2 << bits) - ((size_t)2 << (bits - l - 1)));
+        for (u32 first = 0; first < P; first += blockDim.x >> 4) {
+            if (first + ((threadIdx.x >> 6) << 2) < P) {  // wave-uniform: this wave's four groups hold at least one live node
+                const u32 idx = first + g;
+                const bool live = idx < P;
+                const size_t node = (size_t)blockIdx.x * P + (live ? idx : 0);
+                u64 w = (live && i < 8) ? base[off_c + 8 * node + i] : 0;
+                w = glf::poseidon_coop(w, i);
+                if (live && i < 4) base[off_p + 4 * node + i] = w;
+            }
+        }
+        __syncthreads();
     }
 }
 

@@ -223,10 +223,11 @@ static int ntt_big(p2_circuit* C, const char* name, const u64* in, u64* out, con
     if (it == C->pass1_out_tw.end()) return set_error("internal: no pass-1 twiddle table for this transform"), P2_ERR_INVALID;
     a.out_tw = it->second;
     a.xcd_swizzle = (cosets > 1 && !in_coset_blocks && !C->opt_pass1_noswizzle) ? 1 : 0;  // only where workgroups share their input
+    const std::string name1 = std::string(name) + "_pass1";  // the two passes are timed apart
     if (C->opt_pass1_radix2)
-        LAUNCH(C, name, k_ntt_pass1, dim3(tiles * cols * cosets, batch), dim3(256), (size_t)8 << 12, a);
+        LAUNCH(C, name1, k_ntt_pass1, dim3(tiles * cols * cosets, batch), dim3(256), (size_t)8 << 12, a);
     else
-        LAUNCH(C, name, k_ntt_pass1_r16, dim3(tiles * cols * cosets, batch), dim3(256), r16_lds_bytes(12), a);
+        LAUNCH(C, name1, k_ntt_pass1_r16, dim3(tiles * cols * cosets, batch), dim3(256), r16_lds_bytes(12), a);
     // pass 2: every row of n2 contiguous points, in place
     if (out_col_stride != ((size_t)cosets << logn)) return set_error("internal: two-pass NTT needs densely packed output blocks"), P2_ERR_INVALID;
     NttArgs b{};
@@ -318,7 +319,12 @@ static int merkle_levels(p2_circuit* C, Tree& t, u32 batch) {
         size_t off_p = 4 * (((size_t)2 << t.bits) - ((size_t)2 << (t.bits - l - 1)));
         LAUNCH(C, "merkle_level", k_merkle_level, g1(parents, 256, batch), dim3(256), 0, t.dig + off_c, t.dig + off_p, parents, t.stride());
     }
-    if (fused) LAUNCH(C, "merkle_top", k_merkle_top, dim3(1u << cap_h, batch), dim3(top_threads), 0, t.dig, t.stride(), t.bits, levels - fused, fused);
+    if (fused) {
+        // parents per cap subtree at the fused levels: 2^(fused-1) .. 1; those with more than 32 one thread per node, the rest cooperative
+        const u32 direct = fused > 6 ? fused - 6 : 0;
+        if (direct) LAUNCH(C, "merkle_top", k_merkle_top, dim3(1u << cap_h, batch), dim3(top_threads), 0, t.dig, t.stride(), t.bits, levels - fused, direct);
+        LAUNCH(C, "merkle_top", k_merkle_top_coop, dim3(1u << cap_h, batch), dim3(256), 0, t.dig, t.stride(), t.bits, levels - fused + direct, fused - direct);
+    }
     return 0;
 }
 static int merkle_build(p2_circuit* C, const u64* data, u32 cols, u32 active, size_t col_stride, size_t batch_stride, Tree& t, u32 batch) {

@@ -516,6 +516,28 @@ def test_options_change_scheduling_not_proofs(gpu):
         data2.set_option("streams", 99)
 
 
+def test_schedule_switches_change_scheduling_not_proofs(gpu, monkeypatch):
+    """Round 3's load-time choices -- the witness schedule (chains of up to 8 lookup-free ops on the critical path, or none), the
+    fused Merkle top with its cooperative narrow levels (batches <= 16 only), the register-blocked first NTT pass -- must not
+    show in a single proof byte: the same 20 witnesses through a default handle (batch 20: one launch per Merkle level) and, one
+    by one and in small batches, through handles loaded with every switch flipped."""
+    data, pws, _ = circuits.encrypt(gpu, 4, 64, False, keys=[(bytes([i] * 16), bytes([i + 1] * 12), bytes((7 * i + j) & 0xFF for j in range(64))) for i in range(20)])
+    ref, st = data.prove_batch(pws)
+    assert st == [0] * 20 and len(set(ref)) == 20
+    small, st = data.prove_batch(pws[:3])                       # batch <= 16: fused Merkle top
+    assert st == [0] * 3 and small == ref[:3]
+    for env in ({"P2AES_WITNESS_FUSE": "1"}, {"P2AES_WITNESS_FUSE": "4", "P2AES_MERKLE_TOP": "0"}, {"P2AES_PASS1_RADIX2": "1", "P2AES_PASS1_NOSWIZZLE": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        other = gpu.CircuitData(data.blob)
+        other.gpu()                                             # the switches are read when the handle is loaded
+        for k in env:
+            monkeypatch.delenv(k)
+        assert other.prove(pws[5]) == ref[5]
+        got, st = other.prove_batch(pws[:18])
+        assert st == [0] * 18 and got == ref[:18]
+
+
 def test_failed_workspace_allocation_is_rolled_back(gpu, monkeypatch):
     """a hipMalloc failure in the middle of alloc_workspace must leave the handle without workspaces (error
     code, no kernels on null pointers) and a later call must allocate afresh and succeed."""
