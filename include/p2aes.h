@@ -196,7 +196,7 @@ typedef struct {
 } p2_circuit_info;
 int p2_blob_info(const uint8_t* blob, size_t len, p2_circuit_info* out);
 /* The device-side schedule of a compiled circuit's witness program for macro size `fuse` (csrc/witness_schedule.h; the prover
- * builds it at p2_circuit_load; P2AES_WITNESS_FUSE, default and maximum 8), computed AND checked on the host, no device needed:
+ * builds it at p2_circuit_load; P2AES_WITNESS_FUSE = longest chain, 1..8, default 1 = none), computed AND checked on the host:
  * every op is kept, every slot keeps its first producer, and every operand of every op is produced in an earlier level
  * or earlier in the op's own chain.  out = {levels, chains, longest chain, ops fused into chains}.  P2_ERR_INVALID if a
  * check fails. */

@@ -623,7 +623,9 @@ __device__ __forceinline__ void ntt_p1_load_tw(u64* w, const u64* __restrict__ t
             if (j < half) w[base + j] = tw[(size_t)((tp + ((u32)j << m)) >> log_T) << (tw_log - q)];
     }
 }
-__global__ __launch_bounds__(256, 4) void k_ntt_pass1_r16(Pass1Args a) {
+// MINW = waves per SIMD the register budget is cut for: 4 -> 128 VGPRs with 60 bytes of scratch per lane, 2 -> 178 VGPRs and none
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void k_ntt_pass1_r16(Pass1Args a) {
     extern __shared__ __align__(16) u64 lds[];
     const u32 T = 1u << a.log_T, t = threadIdx.x;
     const int log_n2 = a.logn - a.log_n1;
@@ -641,9 +643,16 @@ __global__ __launch_bounds__(256, 4) void k_ntt_pass1_r16(Pass1Args a) {
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const u32 e = t + 256 * k;
-        const u32 idx = (e >> a.log_T) * n2 + j2_0 + (e & (T - 1));  // < n <= 2^22
-        x[k] = in[idx];
-        if (pre) x[k] = gl::mul_nb(x[k], pre[idx]);
+        x[k] = in[(e >> a.log_T) * n2 + j2_0 + (e & (T - 1))];  // all sixteen loads in flight first
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 e = t + 256 * k;
+        const u32 row = e >> a.log_T, j2 = j2_0 + (e & (T - 1));  // idx = row * n2 + j2 < n <= 2^22
+        // coset scale s^idx = s^(row n2) s^j2: two factors from the hot corner of the table (n1 strided + n2 leading entries per
+        // coset, L2-resident for every tile, column and proof) instead of a third 8 n-byte stream per (column, coset) -- measured
+        // at n = 2^19: pass 1 moved twice the bytes of pass 2 through L2 / Infinity Cache and took as long for 7 of the 19 stages
+        if (pre) x[k] = gl::mul_nb(gl::mul_nb(x[k], pre[row * n2]), pre[j2]);
     }
     const int rem = (a.log_n1 & 3) ? (a.log_n1 & 3) : 4;
     ntt_p1_load_tw(w, a.tw, t, 8, a.log_T, a.logn, rem);
@@ -684,8 +693,10 @@ __global__ __launch_bounds__(256, 4) void k_ntt_pass1_r16(Pass1Args a) {
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const u32 e = t + 256 * k;
-        const u32 o = (e >> a.log_T) * n2 + j2_0 + (e & (T - 1));
-        out[o] = gl::mul_nb(fin.at(lds, k), a.out_tw[o]);
+        const u32 row = e >> a.log_T, tt = e & (T - 1), o = row * n2 + j2_0 + tt;
+        // w^(k1 j2) = w^(k1 j2_0) w^(k1 tt), k1 = rev(row): again two hot entries (column 0 of this tile, the first T columns of the
+        // table) instead of streaming the whole [n1][n2] table per (column, coset)
+        out[o] = gl::mul_nb(gl::mul_nb(fin.at(lds, k), a.out_tw[row * n2 + j2_0]), a.out_tw[row * n2 + tt]);
     }
 }
 // out_tw[r * n2 + j2] = tw[rev(r) * j2]   (r < n1, j2 < n2; tw = w^i, i < n)
@@ -869,7 +880,10 @@ __device__ __forceinline__ int witness_exec_chain(const WitnessArgs& a, u64* val
 // One workgroup generates one witness.  The program is scheduled (witness_schedule.h) into levels; a level holds a few CHAINS
 // (the contracted critical path: each run in order by one thread) and many independent SINGLE ops, WITNESS_MLP of which a
 // thread keeps in flight together; a workgroup barrier separates the levels.  The descriptors are shared by all proofs.
-template <bool HAS_POSEIDON>
+// CHAINS = false: the instantiation for schedules without chains (P2AES_WITNESS_FUSE=1, or a circuit whose critical path holds
+// nothing to fuse); it does not carry the chain executor's registers (252 -> ~100 VGPRs), so its 8 waves share a compute unit
+// with the other stream's hash waves instead of needing an empty one.
+template <bool HAS_POSEIDON, bool CHAINS>
 __global__ __launch_bounds__(512) void k_witness(WitnessArgs a) {
     __shared__ int s_status;
     const u32 proof = blockIdx.x;
@@ -920,9 +934,11 @@ __global__ __launch_bounds__(512) void k_witness(WitnessArgs a) {
         }
         int worst = 0;
         // the contracted critical path first: it is what the next level waits for
-        for (u32 ci = threadIdx.x; ci < L.chain_count; ci += blockDim.x) {
-            const p2::WChain ch = a.chains[L.chain_begin + ci];
-            worst = max(worst, witness_exec_chain(a, val, ch.start, min(ch.count, (u32)WITNESS_KMAX)));
+        if (CHAINS) {
+            for (u32 ci = threadIdx.x; ci < L.chain_count; ci += blockDim.x) {
+                const p2::WChain ch = a.chains[L.chain_begin + ci];
+                worst = max(worst, witness_exec_chain(a, val, ch.start, min(ch.count, (u32)WITNESS_KMAX)));
+            }
         }
         // stages of a single op: descriptor, then every operand together with the present value of the output slot (it does
         // not depend on the operands), then the table entry of a lookup; WITNESS_MLP ops go through them side by side

@@ -75,7 +75,7 @@ struct p2_circuit {
     Op* d_ops = nullptr;
     WLevel* d_wlevels = nullptr;
     WChain* d_wchains = nullptr;
-    u32 witness_levels = 0;
+    u32 witness_levels = 0, witness_chains = 0;
     int32_t* d_wire_slot = nullptr;
     u64* d_lut_ent = nullptr;
     u32 *d_lut_pairs = nullptr, *d_lut_offsets = nullptr, *d_num_lookups = nullptr;
@@ -117,9 +117,14 @@ struct p2_circuit {
     size_t opt_chunk = 128, opt_streams = 2;
     std::map<const u64*, u64*> pass1_out_tw;  // two-pass NTT: output-twiddle table per full twiddle table (ensure_pass1_table)
     bool opt_merkle_top = true;               // P2AES_MERKLE_TOP=0: every level its own launch (A/B measurements)
+    int opt_pass1_waves = 4;                  // P2AES_PASS1_WAVES=2: the 178-register, scratch-free build of the pass-1 kernel (A/B measurements)
     bool opt_pass1_noswizzle = false;         // P2AES_PASS1_NOSWIZZLE: pass-1 workgroups in launch order (A/B measurements)
     bool opt_pass1_radix2 = false;            // P2AES_PASS1_RADIX2: the round-2 pass-1 kernel (A/B measurements)
-    u32 opt_witness_fuse = 8;  // most ops per witness macro (P2AES_WITNESS_FUSE at load; 1 = one op per thread per level)
+    // Longest chain of the witness schedule (P2AES_WITNESS_FUSE at load, 1..8).  Default 1 = no chains: measured on the 64 KiB
+    // circuit, chains of 8 cut the levels from 12.4 k to 2.6 k and change nothing (73 vs 66 ms per 16 witnesses, 17.4 vs 17.6
+    // proofs/s) -- the kernel is bound by one compute unit's address path, not by its depth -- and the chain executor costs
+    // 252 VGPRs against 126.  The contraction is what a several-CUs-per-witness kernel would need; it stays selectable.
+    u32 opt_witness_fuse = 1;
     bool opt_debug_timing = false;
     // host-path staging (p2_prove_batch): persistent device buffers + pinned host buffers, one set per concurrent caller
     std::vector<struct Staging*> staging_free;
@@ -226,8 +231,10 @@ static int ntt_big(p2_circuit* C, const char* name, const u64* in, u64* out, con
     const std::string name1 = std::string(name) + "_pass1";  // the two passes are timed apart
     if (C->opt_pass1_radix2)
         LAUNCH(C, name1, k_ntt_pass1, dim3(tiles * cols * cosets, batch), dim3(256), (size_t)8 << 12, a);
+    else if (C->opt_pass1_waves == 2)
+        LAUNCH(C, name1, k_ntt_pass1_r16<2>, dim3(tiles * cols * cosets, batch), dim3(256), r16_lds_bytes(12), a);
     else
-        LAUNCH(C, name1, k_ntt_pass1_r16, dim3(tiles * cols * cosets, batch), dim3(256), r16_lds_bytes(12), a);
+        LAUNCH(C, name1, k_ntt_pass1_r16<4>, dim3(tiles * cols * cosets, batch), dim3(256), r16_lds_bytes(12), a);
     // pass 2: every row of n2 contiguous points, in place
     if (out_col_stride != ((size_t)cosets << logn)) return set_error("internal: two-pass NTT needs densely packed output blocks"), P2_ERR_INVALID;
     NttArgs b{};
@@ -366,6 +373,7 @@ static int circuit_setup(p2_circuit* C) {
         WitnessSchedule ws = schedule_witness(c, std::min<u32>(C->opt_witness_fuse, WITNESS_KMAX));
         if (ws.max_chain > (u32)WITNESS_KMAX) return set_error("internal: witness chain longer than the kernel is unrolled for"), P2_ERR_INVALID;
         C->witness_levels = (u32)ws.levels.size();
+        C->witness_chains = (u32)ws.chains.size();
         if (upload(C, &C->d_ops, ws.ops.data(), ws.ops.size())) return P2_ERR_HIP;
         if (upload(C, &C->d_wlevels, ws.levels.data(), ws.levels.size())) return P2_ERR_HIP;
         if (upload(C, &C->d_wchains, ws.chains.data(), ws.chains.size())) return P2_ERR_HIP;
@@ -710,10 +718,17 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
         // the wide kernels -- and a deep circuit's witness time is never hidden.  Chained, chunk k+1's witness runs
         // under chunk k's commitments.
         if (C->witness_recorded) HIPCHECK(hipStreamWaitEvent(C->cur->stream, C->ev_witness, 0));
-        if (c.poseidon_rows.empty())
-            LAUNCH(C, "witness", k_witness<false>, dim3(B), dim3(WITNESS_THREADS), 0, a);
-        else
-            LAUNCH(C, "witness", k_witness<true>, dim3(B), dim3(WITNESS_THREADS), 0, a);
+        if (c.poseidon_rows.empty()) {
+            if (C->witness_chains)
+                LAUNCH(C, "witness", (k_witness<false, true>), dim3(B), dim3(WITNESS_THREADS), 0, a);
+            else
+                LAUNCH(C, "witness", (k_witness<false, false>), dim3(B), dim3(WITNESS_THREADS), 0, a);
+        } else {
+            if (C->witness_chains)
+                LAUNCH(C, "witness", (k_witness<true, true>), dim3(B), dim3(WITNESS_THREADS), 0, a);
+            else
+                LAUNCH(C, "witness", (k_witness<true, false>), dim3(B), dim3(WITNESS_THREADS), 0, a);
+        }
         HIPCHECK(hipEventRecord(C->ev_witness, C->cur->stream));
         C->witness_recorded = true;
     }
@@ -1120,6 +1135,7 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
         if (const char* e = getenv("P2AES_STREAMS")) C->opt_streams = (size_t)std::min(8, std::max(1, atoi(e)));
         C->opt_pass1_radix2 = getenv("P2AES_PASS1_RADIX2") != nullptr;
         C->opt_pass1_noswizzle = getenv("P2AES_PASS1_NOSWIZZLE") != nullptr;
+        if (const char* e = getenv("P2AES_PASS1_WAVES")) C->opt_pass1_waves = atoi(e) == 2 ? 2 : 4;
         if (const char* e = getenv("P2AES_MERKLE_TOP")) C->opt_merkle_top = atoi(e) != 0;
         if (const char* e = getenv("P2AES_WITNESS_FUSE")) C->opt_witness_fuse = (u32)std::min(1024, std::max(1, atoi(e)));
         C->opt_debug_timing = getenv("P2AES_DEBUG_TIMING") != nullptr;
@@ -1133,7 +1149,8 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
             hipFuncSetAttribute((const void*)k_ntt_r16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r16_lds_bytes(13)) != hipSuccess)
             throw std::runtime_error("cannot raise the dynamic LDS limit for the NTT kernels");
         if (hipFuncSetAttribute((const void*)k_ntt_pass1, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_ntt_pass1_r16, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+            hipFuncSetAttribute((const void*)k_ntt_pass1_r16<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_ntt_pass1_r16<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
             throw std::runtime_error("cannot set the dynamic LDS limit of the pass-1 NTT");
         // opening maps
         const u32 np = c.num_preprocessed(), W = c.cfg.num_wires, zc = c.num_zs_cols(), qc = c.num_quotient_cols(), NC = c.cfg.num_challenges;
@@ -1686,6 +1703,9 @@ struct PrimCtx {
         C.d_tw_inv = C.d_tw_inv_full;
         if (ensure_pass1_table(&C, C.d_tw_fwd_full, (u32)degree_bits) || ensure_pass1_table(&C, C.d_tw_inv_full, (u32)degree_bits)) return P2_ERR_HIP;
         C.opt_pass1_radix2 = getenv("P2AES_PASS1_RADIX2") != nullptr;
+        if (const char* e = getenv("P2AES_PASS1_WAVES")) C.opt_pass1_waves = atoi(e) == 2 ? 2 : 4;
+        HIPCHECK(hipFuncSetAttribute((const void*)k_ntt_pass1_r16<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void*)k_ntt_pass1_r16<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         std::vector<u64> bases(8);
         u64 wl = gl::root_of_unity(degree_bits + 3);
         for (u32 j = 0; j < 8; j++) bases[j] = gl::mul(gl::MULT_GEN, gl::pow(wl, j));

@@ -517,7 +517,7 @@ def test_options_change_scheduling_not_proofs(gpu):
 
 
 def test_schedule_switches_change_scheduling_not_proofs(gpu, monkeypatch):
-    """Round 3's load-time choices -- the witness schedule (chains of up to 8 lookup-free ops on the critical path, or none), the
+    """Round 3's load-time choices -- the witness schedule (no chains by default, or chains of up to 8 lookup-free ops on the critical path), the
     fused Merkle top with its cooperative narrow levels (batches <= 16 only), the register-blocked first NTT pass -- must not
     show in a single proof byte: the same 20 witnesses through a default handle (batch 20: one launch per Merkle level) and, one
     by one and in small batches, through handles loaded with every switch flipped."""
@@ -526,7 +526,8 @@ def test_schedule_switches_change_scheduling_not_proofs(gpu, monkeypatch):
     assert st == [0] * 20 and len(set(ref)) == 20
     small, st = data.prove_batch(pws[:3])                       # batch <= 16: fused Merkle top
     assert st == [0] * 3 and small == ref[:3]
-    for env in ({"P2AES_WITNESS_FUSE": "1"}, {"P2AES_WITNESS_FUSE": "4", "P2AES_MERKLE_TOP": "0"}, {"P2AES_PASS1_RADIX2": "1", "P2AES_PASS1_NOSWIZZLE": "1"}):
+    for env in ({"P2AES_WITNESS_FUSE": "8"}, {"P2AES_WITNESS_FUSE": "4", "P2AES_MERKLE_TOP": "0"}, {"P2AES_PASS1_RADIX2": "1", "P2AES_PASS1_NOSWIZZLE": "1"},
+                {"P2AES_PASS1_WAVES": "2"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         other = gpu.CircuitData(data.blob)
