@@ -623,7 +623,8 @@ __device__ __forceinline__ void ntt_p1_load_tw(u64* w, const u64* __restrict__ t
             if (j < half) w[base + j] = tw[(size_t)((tp + ((u32)j << m)) >> log_T) << (tw_log - q)];
     }
 }
-// MINW = waves per SIMD the register budget is cut for: 4 -> 128 VGPRs with 60 bytes of scratch per lane, 2 -> 178 VGPRs and none
+// MINW = waves per SIMD the register budget is cut for: 4 -> 128 VGPRs with 44 bytes of scratch per lane, 2 -> 170 VGPRs and none
+// (measured at n = 2^19: the scratch-free build at half the occupancy is 1.5 x slower, 100.8 vs 67.3 ms per 16 proofs)
 template <int MINW>
 __global__ __launch_bounds__(256, MINW) void k_ntt_pass1_r16(Pass1Args a) {
     extern __shared__ __align__(16) u64 lds[];
@@ -643,16 +644,12 @@ __global__ __launch_bounds__(256, MINW) void k_ntt_pass1_r16(Pass1Args a) {
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const u32 e = t + 256 * k;
-        x[k] = in[(e >> a.log_T) * n2 + j2_0 + (e & (T - 1))];  // all sixteen loads in flight first
-    }
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const u32 e = t + 256 * k;
-        const u32 row = e >> a.log_T, j2 = j2_0 + (e & (T - 1));  // idx = row * n2 + j2 < n <= 2^22
-        // coset scale s^idx = s^(row n2) s^j2: two factors from the hot corner of the table (n1 strided + n2 leading entries per
-        // coset, L2-resident for every tile, column and proof) instead of a third 8 n-byte stream per (column, coset) -- measured
-        // at n = 2^19: pass 1 moved twice the bytes of pass 2 through L2 / Infinity Cache and took as long for 7 of the 19 stages
-        if (pre) x[k] = gl::mul_nb(gl::mul_nb(x[k], pre[row * n2]), pre[j2]);
+        const u32 idx = (e >> a.log_T) * n2 + j2_0 + (e & (T - 1));  // < n <= 2^22
+        x[k] = in[idx];
+        // (the coset scale s^idx as s^(row n2) s^j2 from the hot corner of the table -- two multiplies instead of an 8 n-byte
+        // stream per (column, coset) -- was measured at n = 2^19 and is slower, 67.3 vs 61.7 ms per 16 proofs: the kernel is
+        // VALU bound, not waiting on these streams; likewise the output twiddle below)
+        if (pre) x[k] = gl::mul_nb(x[k], pre[idx]);
     }
     const int rem = (a.log_n1 & 3) ? (a.log_n1 & 3) : 4;
     ntt_p1_load_tw(w, a.tw, t, 8, a.log_T, a.logn, rem);
@@ -693,10 +690,8 @@ __global__ __launch_bounds__(256, MINW) void k_ntt_pass1_r16(Pass1Args a) {
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const u32 e = t + 256 * k;
-        const u32 row = e >> a.log_T, tt = e & (T - 1), o = row * n2 + j2_0 + tt;
-        // w^(k1 j2) = w^(k1 j2_0) w^(k1 tt), k1 = rev(row): again two hot entries (column 0 of this tile, the first T columns of the
-        // table) instead of streaming the whole [n1][n2] table per (column, coset)
-        out[o] = gl::mul_nb(gl::mul_nb(fin.at(lds, k), a.out_tw[row * n2 + j2_0]), a.out_tw[row * n2 + tt]);
+        const u32 o = (e >> a.log_T) * n2 + j2_0 + (e & (T - 1));
+        out[o] = gl::mul_nb(fin.at(lds, k), a.out_tw[o]);
     }
 }
 // out_tw[r * n2 + j2] = tw[rev(r) * j2]   (r < n1, j2 < n2; tw = w^i, i < n)
