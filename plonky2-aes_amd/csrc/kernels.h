@@ -552,6 +552,10 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
     }
 }
 
+// (Round 3 measured a radix-8 form of the half-column kernel -- 8 points per thread, 64 bytes of LDS per thread, two 1 024-thread
+// workgroups per compute unit = 8 waves per SIMD instead of 4, one more exchange: 21.4 ms against 19.7 ms per 128-proof chunk.
+// Occupancy is not what this kernel lacks; the variant was dropped.)
+
 // ---- large transforms (n > 2^14): four-step split n = n1 * n2.  Pass 1 (this kernel): for a tile of T adjacent
 // columns j2, the n1-point DIF over the stride-n2 elements x[j1*n2 + j2], then the twiddle w_n^(j2*k1); the result
 // for k1 lands in row rev(k1).  Pass 2 is k_ntt_lds on the n1 contiguous rows of n2 points.  Together: natural

@@ -1,5 +1,6 @@
 // Poseidon-12 for the hashing kernels: same permutation as gl::poseidon (gl.h), restructured for VALU issue slots
-// (18.9 k VALU instructions per permutation; the plain 30-round form compiles to 41 k):
+// (15.5 k VALU instructions per permutation, PMC-counted: profiles/r02_valu.json, r03_valu.json; the plain 30-round form
+// compiles to 41 k, round 1's restructuring to 28 k):
 //   * lazy reduction -- state words are arbitrary u64 representatives (not < p) inside the permutation; every product is
 //     reduced once from 128 bits without canonicalisation; outputs are canonicalised;
 //   * multiply-reduce built from v_mad_u64_u32 (gl::mulr_add_dev): the mad is a 64-bit adder with a free multiplier and a
@@ -427,7 +428,7 @@ GL_HD void poseidon(u64* s) {
 // ---- cooperative form: ONE sponge state spread over 12 lanes of a 16-lane group (lane i holds word i; lanes 12..15 are
 // idle and must hold 0).  Same permutation, same constants; the linear layers gather the other words with cross-lane
 // reads (ds_bpermute) and the partial rounds' dot product is a 4-step butterfly sum.  4.3 k VALU instructions per lane
-// instead of 18.9 k: this is for the Fiat-Shamir chain (k_challenger), where ~110 permutations per proof are strictly
+// instead of 15.5 k: this is for the Fiat-Shamir chain (k_challenger), where ~110 permutations per proof are strictly
 // sequential and a thread-per-sponge kernel leaves a single proof waiting on one lane's instruction stream.
 __device__ __forceinline__ u64 shfl64(u64 v, int src_lane) { return (u64)__shfl((unsigned long long)v, src_lane, 64); }
 __device__ inline u64 poseidon_coop(u64 w, const u32 i /* lane within the 16-lane group */) {

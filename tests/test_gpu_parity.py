@@ -50,7 +50,7 @@ def test_poseidon_permutation(gpu, orc):
         assert list(s) == list(buf[12 * i:12 * i + 12])
 
 
-@pytest.mark.parametrize("bits", [1, 2, 4, 7, 11, 14, 15, 16, 17, 18, 19])
+@pytest.mark.parametrize("bits", [1, 2, 4, 7, 11, 12, 13, 14, 15, 16, 17, 18, 19])
 def test_intt_and_lde(gpu, orc, bits):
     r = random.Random(bits)
     # > 14 bits exercises the two-pass (four-step) transform; 15..19 cover every shape of its register-blocked first pass
