@@ -84,6 +84,25 @@ def kernel_bytes(name, info, active_wires=80):
     return None
 
 
+def load_profile(kind, root=ROOT, tag=None):
+    """profiles/<tag>_<kind>.json (written by tools/pmc_traffic.py / pmc_valu.py from rocprofv3 PMC passes) and where it came from.
+    The counter files are evidence taken on ONE build: each records the identity of the kernel sources it was measured on
+    (tools/src_id.py) and is used only while that matches the sources this run is built from -- otherwise the data is None and
+    the source record says "stale", instead of silently pricing another binary."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from src_id import csrc_id
+    here = csrc_id()["csrc_sha16"]
+    path = os.path.join("profiles", (tag or PROFILE_TAG) + "_" + kind + ".json")
+    try:
+        j = json.load(open(os.path.join(root, path)))
+    except Exception:  # noqa: BLE001
+        return None, {"file": path, "status": "missing"}
+    src = j.get("source", {})
+    ok = src.get("csrc_sha16") == here
+    return (j if ok else None), {"file": path, "measured_on_csrc_sha16": src.get("csrc_sha16"), "git_head": src.get("git_head"), "this_build_csrc_sha16": here,
+                                 "status": "current" if ok else "stale: measured on other kernel sources"}
+
+
 def spawn_ranks(n):
     """One process per GPU on this node: python -m torch.distributed.run --nproc-per-node n bench.py <same argv>."""
     import socket
@@ -293,20 +312,8 @@ def main():
         # The counter files are evidence taken on ONE build: each records the identity of the kernel sources it was measured on
         # (tools/src_id.py) and is used only while that matches the sources this run is built from -- otherwise the field is
         # null and *_source says "stale", instead of silently pricing another binary.
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        from src_id import csrc_id
-        here = csrc_id()["csrc_sha16"]
-
         def profile(kind):
-            path = os.path.join("profiles", PROFILE_TAG + "_" + kind + ".json")
-            try:
-                j = json.load(open(os.path.join(ROOT, path)))
-            except Exception:  # noqa: BLE001
-                return None, {"file": path, "status": "missing"}
-            src = j.get("source", {})
-            ok = src.get("csrc_sha16") == here
-            return (j if ok else None), {"file": path, "measured_on_csrc_sha16": src.get("csrc_sha16"), "git_head": src.get("git_head"), "this_build_csrc_sha16": here,
-                                         "status": "current" if ok else "stale: measured on other kernel sources"}
+            return load_profile(kind)
         traffic = None
         tj, traffic_source = profile("traffic")
         try:  # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x2 per calibration, WRITE_SIZE), profiles/

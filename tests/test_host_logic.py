@@ -687,3 +687,31 @@ def test_witness_schedule_contracts_the_counter_chain_of_a_deep_circuit(pkg):
     data = circuits.encrypt(pkg, 4, 2048, False)[0]
     one, eight = data.witness_schedule(1), data.witness_schedule(8)
     assert eight["levels"] * 2 < one["levels"] and eight["fused_ops"] * 50 < data.info["num_ops"]
+
+
+def test_bench_uses_a_counter_file_only_for_the_sources_it_was_measured_on(tmp_path):
+    """bench.py's roofline.traffic / roofline_valu come from rocprofv3 PMC passes kept under profiles/ (they went
+    stale silently).  Each file records the identity of the kernel sources it was measured on; bench.py uses it only while that
+    matches the sources it runs on and says so in the line (`traffic_source` / `valu_source`)."""
+    import importlib.util
+    import json
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from src_id import csrc_id
+    here = csrc_id()["csrc_sha16"]
+    (tmp_path / "profiles").mkdir()
+    data, src = bench.load_profile("traffic", root=str(tmp_path), tag="t")
+    assert data is None and src["status"] == "missing"
+    (tmp_path / "profiles" / "t_traffic.json").write_text(json.dumps({"source": {"csrc_sha16": "0" * 16, "git_head": "abc"}, "chunk": 128}))
+    data, src = bench.load_profile("traffic", root=str(tmp_path), tag="t")
+    assert data is None and src["status"].startswith("stale") and src["measured_on_csrc_sha16"] == "0" * 16 and src["this_build_csrc_sha16"] == here
+    (tmp_path / "profiles" / "t_traffic.json").write_text(json.dumps({"source": {"csrc_sha16": here}, "chunk": 128}))
+    data, src = bench.load_profile("traffic", root=str(tmp_path), tag="t")
+    assert data["chunk"] == 128 and src["status"] == "current"
+    # the files committed for this round were measured on the committed kernels
+    for kind in ("traffic", "valu"):
+        data, src = bench.load_profile(kind)
+        assert src["status"] == "current", src
