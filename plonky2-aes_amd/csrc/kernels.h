@@ -666,29 +666,22 @@ __global__ __launch_bounds__(256, MINW) void k_ntt_pass1_r16(Pass1Args a) {
         const int m = logN - 4;
         const u32 tp = t & ((1u << m) - 1);
         ntt_p1_load_tw(w, a.tw, tp, m, a.log_T, a.logn, 4);  // in flight across the barrier
-        {
-            const NttLdsWalk wr(base_idx, stride);
+        // (padded index computed per point, not NttLdsWalk: the last step's stride is T, which is 8 or 4 for n >= 2^21, and
+        // the walk's affine step holds only for strides that are 1 or a multiple of 16)
 #pragma unroll
-            for (int r = 0; r < 16; r++) wr.at(lds, r) = x[r];
-        }
+        for (int r = 0; r < 16; r++) lds[ntt_pad(base_idx + (u32)r * stride)] = x[r];
         __syncthreads();
         base_idx = ((t >> m) << logN) | tp;
         stride = 1u << m;
-        {
-            const NttLdsWalk rd(base_idx, stride);
 #pragma unroll
-            for (int r = 0; r < 16; r++) x[r] = rd.at(lds, r);
-        }
+        for (int r = 0; r < 16; r++) x[r] = lds[ntt_pad(base_idx + (u32)r * stride)];
         ntt_r16_stage<0>(x, w);
         ntt_r16_stage<1>(x, w);
         ntt_r16_stage<2>(x, w);
         ntt_r16_stage<3>(x, w);
     }
-    {
-        const NttLdsWalk wr(base_idx, stride);
 #pragma unroll
-        for (int r = 0; r < 16; r++) wr.at(lds, r) = x[r];
-    }
+    for (int r = 0; r < 16; r++) lds[ntt_pad(base_idx + (u32)r * stride)] = x[r];
     __syncthreads();
     const NttLdsWalk fin(t, 256);
 #pragma unroll

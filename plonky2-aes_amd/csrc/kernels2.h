@@ -63,8 +63,14 @@ struct AlphaAcc {
 // argument with the ArithmeticGate constraints riding along (a chunk of 8 wires is exactly two arithmetic ops), once for the
 // LookupTableGate and LookupGate views together (6 columns = 2 table slots + 3 looking slots).  Round 1 walked them once per
 // view (4x) and fetched 2.3x its algorithmic bytes (profiles/r01_traffic.json; the very first version 3.8x).
-template <bool HAS_POSEIDON>
+// ONE_WALK (round 3; standard config without PoseidonGate rows: 80 routed wires, chunks of 8): the wire columns are read ONCE.
+// The permutation argument takes them 8 at a time; a LookupTableGate slot is 3 consecutive columns and a LookupGate slot 2, so
+// while a chunk of 8 sits in registers every slot that ENDS inside it is fed -- its leading columns are either in the same
+// chunk or the last two of the previous one, which are carried over.  Nothing else changes: every accumulator takes exact
+// integer sums (AlphaAcc), so the order in which the terms arrive does not show in the result.
+template <bool HAS_POSEIDON, bool ONE_WALK = false>
 __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
+    static_assert(!(HAS_POSEIDON && ONE_WALK), "the one-walk form rides on the ArithmeticGate layout of routed-only circuits");
     const u32 N = a.n << a.rate_bits;
     const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
@@ -102,41 +108,19 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
         if (kind == p2::G_POSEIDON) f_pos = filter;
     }
     for (u32 i = 0; i < a.NC; i++) A.add(i, gl::mul(l0, gl::sub(Zs[(size_t)i * N], 1)));
-    {  // permutation argument, both challenges per loaded wire
-        const u64 b0 = cw[CH_BETAS], b1 = cw[CH_BETAS + 1], g0 = cw[CH_GAMMAS], g1 = cw[CH_GAMMAS + 1];
-        const u64 bx0 = gl::mul(b0, x), bx1 = gl::mul(b1, x);
-        for (u32 chunk = 0; chunk <= a.npp; chunk++) {
-            u64 num0 = 1, den0 = 1, num1 = 1, den1 = 1;
-            u32 j1 = min(a.R, (chunk + 1) * a.qdf);
-            u64 w8[8];
-            for (u32 j = chunk * a.qdf; j < j1; j++) {
-                const u64 wv = W[(size_t)j * N], sg = S[(size_t)j * N], kj = a.k_is[j];
-                if (!HAS_POSEIDON) w8[(j - chunk * a.qdf) & 7] = wv;
-                num0 = gl::mul(num0, gl::add(gl::add(wv, gl::mul(bx0, kj)), g0));
-                den0 = gl::mul(den0, gl::add(gl::add(wv, gl::mul(b0, sg)), g0));
-                num1 = gl::mul(num1, gl::add(gl::add(wv, gl::mul(bx1, kj)), g1));
-                den1 = gl::mul(den1, gl::add(gl::add(wv, gl::mul(b1, sg)), g1));
-            }
-            if (!HAS_POSEIDON && f_arith && a.qdf == 8) {
-                // ArithmeticGate ops 2*chunk and 2*chunk + 1 occupy exactly these 8 wires: out - (c0 m0 m1 + c1 addend)
-                for (u32 h = 0; h < 2; h++) {
-                    const u64 m0 = w8[4 * h], m1 = w8[4 * h + 1], ad = w8[4 * h + 2], o = w8[4 * h + 3];
-                    A.add(idx_gate + 2 * chunk + h, gl::mul(f_arith, gl::sub(o, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1)))));
-                }
-            }
-            for (u32 i = 0; i < 2; i++) {
-                u64 prev = chunk == 0 ? Zs[(size_t)i * N] : Zs[(size_t)(a.NC + i * a.npp + chunk - 1) * N];
-                u64 next = chunk == a.npp ? Zn[(size_t)i * N] : Zs[(size_t)(a.NC + i * a.npp + chunk) * N];
-                A.add(idx_pp + i * (a.npp + 1) + chunk, gl::sub(gl::mul(prev, i ? num1 : num0), gl::mul(next, i ? den1 : den0)));
-            }
-        }
-    }
+    // ---- lookup argument: state shared by the two forms of the walk
+    const u64* sel = C + (size_t)a.nsel * N;  // TransSre, TransLdc, InitSre, LastLdc, StartEnd..
+    u64 s_sre = 0, s_ldc = 0;
+    const u32 lk0 = a.NC * (1 + a.npp);
+    const u64 *lz[2] = {Zs, Zs}, *lzn[2] = {Zn, Zn};
+    u64 dA[2] = {0, 0}, dB[2] = {0, 0}, dAl[2] = {0, 0}, dD[2] = {0, 0}, cur[2] = {0, 0};
+    u64 tprod[2] = {1, 1}, tsum[2] = {0, 0}, lprod[2] = {1, 1}, lsum[2] = {0, 0};
+    u32 tpoly = 0, tin = 0, lpoly = 0, lin = 0;
+    const u32 lu_deg = a.qdf - 1;
     if (a.nlp) {
-        const u64* sel = C + (size_t)a.nsel * N;  // TransSre, TransLdc, InitSre, LastLdc, StartEnd..
-        const u64 s_sre = sel[0], s_ldc = sel[(size_t)1 * N], s_init = sel[(size_t)2 * N], s_last = sel[(size_t)3 * N];
-        const u32 lk0 = a.NC * (1 + a.npp);
-        const u64 *lz[2], *lzn[2];
-        u64 dA[2], dB[2], dAl[2], dD[2], cur[2];
+        s_sre = sel[0];
+        s_ldc = sel[(size_t)1 * N];
+        const u64 s_init = sel[(size_t)2 * N], s_last = sel[(size_t)3 * N];
         for (u32 i = 0; i < 2; i++) {
             const u64* d = cw + CH_DELTAS + 4 * i;
             dA[i] = d[0];
@@ -154,51 +138,108 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
             for (u32 l = 0; l < a.num_luts; l++) A.add(t0 + 3 + l, gl::mul(sel[(size_t)(4 + l) * N], gl::sub(z_re, zv[a.lut_last_row[l]])));
             cur[i] = lzn[i][0];
         }
-        // LookupTableGate view (slots (inp, out, mult): RE Horner and the Sum transition of each partial poly) and
-        // LookupGate view (slots (inp, out): the LDC transition of each partial poly) in ONE walk over the wire columns:
-        // six columns are two table slots and three looking slots (round 1 walked the columns once per view).
-        {
-            u64 tprod[2] = {1, 1}, tsum[2] = {0, 0}, lprod[2] = {1, 1}, lsum[2] = {0, 0};
-            u32 tpoly = 0, tin = 0, lpoly = 0, lin = 0;
-            const u32 lu_deg = a.qdf - 1;
-            auto lut_slot = [&](u32 s_, u64 win, u64 wout, u64 wm) {
-                for (u32 i = 0; i < 2; i++) {
-                    cur[i] = gl::add(gl::mul(cur[i], dD[i]), gl::add(win, gl::mul(dB[i], wout)));
-                    const u64 f = gl::sub(dAl[i], gl::add(win, gl::mul(dA[i], wout)));
-                    tsum[i] = gl::add(gl::mul(tsum[i], f), gl::mul(wm, tprod[i]));  // sum' = sum*f + mult*prod
-                    tprod[i] = gl::mul(tprod[i], f);
+    }
+    // LookupTableGate view (slots (inp, out, mult): RE Horner and the Sum transition of each partial poly) and LookupGate view
+    // (slots (inp, out): the LDC transition of each partial poly)
+    auto lut_slot = [&](u32 s_, u64 win, u64 wout, u64 wm) {
+        for (u32 i = 0; i < 2; i++) {
+            cur[i] = gl::add(gl::mul(cur[i], dD[i]), gl::add(win, gl::mul(dB[i], wout)));
+            const u64 f = gl::sub(dAl[i], gl::add(win, gl::mul(dA[i], wout)));
+            tsum[i] = gl::add(gl::mul(tsum[i], f), gl::mul(wm, tprod[i]));  // sum' = sum*f + mult*prod
+            tprod[i] = gl::mul(tprod[i], f);
+        }
+        if (++tin == a.lut_deg || s_ + 1 == p2::LUT_SLOTS) {
+            for (u32 i = 0; i < 2; i++) {
+                u64 prev = tpoly == 0 ? lzn[i][(size_t)a.nsldc * N] : lz[i][(size_t)tpoly * N];
+                u64 diff = gl::sub(lz[i][(size_t)(1 + tpoly) * N], prev);
+                A.add(idx_lk + i * nlk + 4 + a.num_luts + 2 * tpoly, gl::mul(s_sre, gl::sub(gl::mul(tprod[i], diff), tsum[i])));
+                tprod[i] = 1;
+                tsum[i] = 0;
+            }
+            tpoly++;
+            tin = 0;
+        }
+    };
+    auto lu_slot = [&](u32 s_, u64 win, u64 wout) {
+        for (u32 i = 0; i < 2; i++) {
+            const u64 f = gl::sub(dAl[i], gl::add(win, gl::mul(dA[i], wout)));
+            lsum[i] = gl::add(gl::mul(lsum[i], f), lprod[i]);
+            lprod[i] = gl::mul(lprod[i], f);
+        }
+        if (++lin == lu_deg || s_ + 1 == p2::LU_SLOTS) {
+            for (u32 i = 0; i < 2; i++) {
+                u64 prev = lpoly == 0 ? lzn[i][(size_t)a.nsldc * N] : lz[i][(size_t)lpoly * N];
+                u64 diff = gl::sub(lz[i][(size_t)(1 + lpoly) * N], prev);
+                A.add(idx_lk + i * nlk + 4 + a.num_luts + 2 * lpoly + 1, gl::mul(s_ldc, gl::add(gl::mul(lprod[i], diff), lsum[i])));
+                lprod[i] = 1;
+                lsum[i] = 0;
+            }
+            lpoly++;
+            lin = 0;
+        }
+    };
+    static_assert(p2::LUT_SLOTS == 26 && p2::LU_SLOTS == 40, "both walks assume 26 table slots (78 columns) and 40 looking slots (80 columns)");
+    {  // permutation argument, both challenges per loaded wire
+        const u64 b0 = cw[CH_BETAS], b1 = cw[CH_BETAS + 1], g0 = cw[CH_GAMMAS], g1 = cw[CH_GAMMAS + 1];
+        const u64 bx0 = gl::mul(b0, x), bx1 = gl::mul(b1, x);
+        u64 p6 = 0, p7 = 0;  // ONE_WALK: columns 6 and 7 of the previous chunk
+        for (u32 chunk = 0; chunk <= a.npp; chunk++) {
+            u64 num0 = 1, den0 = 1, num1 = 1, den1 = 1;
+            u32 j1 = min(a.R, (chunk + 1) * a.qdf);
+            u64 w8[8];
+            if (ONE_WALK) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const u32 j = 8 * chunk + k;
+                    const u64 wv = W[(size_t)j * N], sg = S[(size_t)j * N], kj = a.k_is[j];
+                    w8[k] = wv;
+                    num0 = gl::mul(num0, gl::add(gl::add(wv, gl::mul(bx0, kj)), g0));
+                    den0 = gl::mul(den0, gl::add(gl::add(wv, gl::mul(b0, sg)), g0));
+                    num1 = gl::mul(num1, gl::add(gl::add(wv, gl::mul(bx1, kj)), g1));
+                    den1 = gl::mul(den1, gl::add(gl::add(wv, gl::mul(b1, sg)), g1));
                 }
-                if (++tin == a.lut_deg || s_ + 1 == p2::LUT_SLOTS) {
-                    for (u32 i = 0; i < 2; i++) {
-                        u64 prev = tpoly == 0 ? lzn[i][(size_t)a.nsldc * N] : lz[i][(size_t)tpoly * N];
-                        u64 diff = gl::sub(lz[i][(size_t)(1 + tpoly) * N], prev);
-                        A.add(idx_lk + i * nlk + 4 + a.num_luts + 2 * tpoly, gl::mul(s_sre, gl::sub(gl::mul(tprod[i], diff), tsum[i])));
-                        tprod[i] = 1;
-                        tsum[i] = 0;
-                    }
-                    tpoly++;
-                    tin = 0;
+            } else {
+                for (u32 j = chunk * a.qdf; j < j1; j++) {
+                    const u64 wv = W[(size_t)j * N], sg = S[(size_t)j * N], kj = a.k_is[j];
+                    if (!HAS_POSEIDON) w8[(j - chunk * a.qdf) & 7] = wv;
+                    num0 = gl::mul(num0, gl::add(gl::add(wv, gl::mul(bx0, kj)), g0));
+                    den0 = gl::mul(den0, gl::add(gl::add(wv, gl::mul(b0, sg)), g0));
+                    num1 = gl::mul(num1, gl::add(gl::add(wv, gl::mul(bx1, kj)), g1));
+                    den1 = gl::mul(den1, gl::add(gl::add(wv, gl::mul(b1, sg)), g1));
                 }
-            };
-            auto lu_slot = [&](u32 s_, u64 win, u64 wout) {
-                for (u32 i = 0; i < 2; i++) {
-                    const u64 f = gl::sub(dAl[i], gl::add(win, gl::mul(dA[i], wout)));
-                    lsum[i] = gl::add(gl::mul(lsum[i], f), lprod[i]);
-                    lprod[i] = gl::mul(lprod[i], f);
+            }
+            if (!HAS_POSEIDON && f_arith && a.qdf == 8) {
+                // ArithmeticGate ops 2*chunk and 2*chunk + 1 occupy exactly these 8 wires: out - (c0 m0 m1 + c1 addend)
+                for (u32 h = 0; h < 2; h++) {
+                    const u64 m0 = w8[4 * h], m1 = w8[4 * h + 1], ad = w8[4 * h + 2], o = w8[4 * h + 3];
+                    A.add(idx_gate + 2 * chunk + h, gl::mul(f_arith, gl::sub(o, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1)))));
                 }
-                if (++lin == lu_deg || s_ + 1 == p2::LU_SLOTS) {
-                    for (u32 i = 0; i < 2; i++) {
-                        u64 prev = lpoly == 0 ? lzn[i][(size_t)a.nsldc * N] : lz[i][(size_t)lpoly * N];
-                        u64 diff = gl::sub(lz[i][(size_t)(1 + lpoly) * N], prev);
-                        A.add(idx_lk + i * nlk + 4 + a.num_luts + 2 * lpoly + 1, gl::mul(s_ldc, gl::add(gl::mul(lprod[i], diff), lsum[i])));
-                        lprod[i] = 1;
-                        lsum[i] = 0;
-                    }
-                    lpoly++;
-                    lin = 0;
+            }
+            for (u32 i = 0; i < 2; i++) {
+                u64 prev = chunk == 0 ? Zs[(size_t)i * N] : Zs[(size_t)(a.NC + i * a.npp + chunk - 1) * N];
+                u64 next = chunk == a.npp ? Zn[(size_t)i * N] : Zs[(size_t)(a.NC + i * a.npp + chunk) * N];
+                A.add(idx_pp + i * (a.npp + 1) + chunk, gl::sub(gl::mul(prev, i ? num1 : num0), gl::mul(next, i ? den1 : den0)));
+            }
+            if (ONE_WALK && a.nlp) {
+                // the slots that end in this chunk: column c = 8 chunk + k closes table slot c / 3 when c % 3 == 2 (c < 78) and
+                // looking slot c / 2 when c is odd; 8 = 2 (mod 3), so the table-slot pattern depends on chunk mod 3 (uniform)
+                const u32 c3 = (2 * chunk) % 3;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const u32 c = 8 * chunk + k;
+                    const u64 wm1 = k >= 1 ? w8[k >= 1 ? k - 1 : 0] : p7, wm2 = k >= 2 ? w8[k >= 2 ? k - 2 : 0] : (k == 1 ? p7 : p6);
+                    if ((c3 + k) % 3 == 2 && c < 3 * p2::LUT_SLOTS) lut_slot(c / 3, wm2, wm1, w8[k]);
+                    if (k & 1) lu_slot(c >> 1, wm1, w8[k]);
                 }
-            };
-            static_assert(p2::LUT_SLOTS == 26 && p2::LU_SLOTS == 40, "the six-column grouping below assumes 26 table slots and 40 looking slots");
+                p6 = w8[6];
+                p7 = w8[7];
+            }
+        }
+    }
+    if (a.nlp) {
+        if (!ONE_WALK) {
+            // both views in ONE walk of their own over the wire columns: six columns are two table slots and three looking slots
+            // (round 1 walked the columns once per view)
             for (u32 g = 0; g < 13; g++) {
                 u64 w[6];
 #pragma unroll
@@ -210,8 +251,8 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
                 lu_slot(3 * g + 2, w[4], w[5]);
             }
             lu_slot(39, W[(size_t)78 * N], W[(size_t)79 * N]);
-            for (u32 i = 0; i < 2; i++) A.add(idx_lk + i * nlk + 3 + a.num_luts, gl::mul(s_sre, gl::sub(lz[i][0], cur[i])));
         }
+        for (u32 i = 0; i < 2; i++) A.add(idx_lk + i * nlk + 3 + a.num_luts, gl::mul(s_sre, gl::sub(lz[i][0], cur[i])));
     }
     // gate constraints: constraint slot k collects every gate's k-th constraint times the gate's filter
     {

@@ -118,6 +118,7 @@ struct p2_circuit {
     std::map<const u64*, u64*> pass1_out_tw;  // two-pass NTT: output-twiddle table per full twiddle table (ensure_pass1_table)
     bool opt_merkle_top = true;               // P2AES_MERKLE_TOP=0: every level its own launch (A/B measurements)
     int opt_pass1_waves = 4;                  // P2AES_PASS1_WAVES=2: the 178-register, scratch-free build of the pass-1 kernel (A/B measurements)
+    bool opt_quotient_two_walks = false;      // P2AES_QUOTIENT_TWO_WALKS: round 2's form of the quotient kernel (A/B measurements)
     bool opt_pass1_noswizzle = false;         // P2AES_PASS1_NOSWIZZLE: pass-1 workgroups in launch order (A/B measurements)
     bool opt_pass1_radix2 = false;            // P2AES_PASS1_RADIX2: the round-2 pass-1 kernel (A/B measurements)
     // Longest chain of the witness schedule (P2AES_WITNESS_FUSE at load, 1..8).  Default 1 = no chains: measured on the 64 KiB
@@ -843,7 +844,10 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
             LAUNCH(C, "alpha_pows", k_alpha_pows, g1(2 * B, 64), dim3(64), 0, C->cur->d_chal, C->cur->d_apow, B, nterms);
         }
         if (c.poseidon_rows.empty())
-            LAUNCH(C, "quotient", k_quotient<false>, g1(N, 256, B), dim3(256), 0, a);
+            if (C->opt_quotient_two_walks)
+                LAUNCH(C, "quotient", (k_quotient<false, false>), g1(N, 256, B), dim3(256), 0, a);
+            else
+                LAUNCH(C, "quotient", (k_quotient<false, true>), g1(N, 256, B), dim3(256), 0, a);  // the wire columns read once
         else
             LAUNCH(C, "quotient", k_quotient<true>, g1(N, 256, B), dim3(256), 0, a);
         // coset-wise inverse transform: residues r_j, then the 8-point cross-coset DFT
@@ -1135,6 +1139,7 @@ p2_circuit* p2_circuit_load(const uint8_t* blob, size_t len, int device) {
         if (const char* e = getenv("P2AES_STREAMS")) C->opt_streams = (size_t)std::min(8, std::max(1, atoi(e)));
         C->opt_pass1_radix2 = getenv("P2AES_PASS1_RADIX2") != nullptr;
         C->opt_pass1_noswizzle = getenv("P2AES_PASS1_NOSWIZZLE") != nullptr;
+        C->opt_quotient_two_walks = getenv("P2AES_QUOTIENT_TWO_WALKS") != nullptr;
         if (const char* e = getenv("P2AES_PASS1_WAVES")) C->opt_pass1_waves = atoi(e) == 2 ? 2 : 4;
         if (const char* e = getenv("P2AES_MERKLE_TOP")) C->opt_merkle_top = atoi(e) != 0;
         if (const char* e = getenv("P2AES_WITNESS_FUSE")) C->opt_witness_fuse = (u32)std::min(1024, std::max(1, atoi(e)));

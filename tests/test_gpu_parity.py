@@ -74,6 +74,28 @@ def test_intt_and_lde(gpu, orc, bits):
         assert list(o) == list(lde[c * 8 * n:(c + 1) * 8 * n])
 
 
+@pytest.mark.parametrize("bits", [20, 21, 22])
+def test_intt_and_lde_largest_sizes(gpu, orc, bits):
+    """The sizes above test_intt_and_lde's reach, through numpy buffers: 2^20 .. 2^22 are the three remaining shapes of the
+    two-pass transform's first pass (8, 9 and 10 stages down the rows of a tile 16, 8 and 4 columns wide).  Round 3's first
+    version of that kernel was wrong for tiles narrower than 16 columns -- n >= 2^21 -- and nothing below 2^21 could see it."""
+    import numpy as np
+    u64p = C.POINTER(C.c_uint64)
+    n = 1 << bits
+    rng = np.random.default_rng(bits)
+    vals = (rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)) % np.uint64(P)
+    vals[:4] = [0, P - 1, 1, P - 2]
+    out, lde = np.zeros(n, dtype=np.uint64), np.zeros(8 * n, dtype=np.uint64)
+    assert gpu.lib().p2_gpu_intt(vals.ctypes.data_as(u64p), 1, bits, out.ctypes.data_as(u64p), 0) == 0, gpu.lib().p2_last_error()
+    assert gpu.lib().p2_gpu_lde(vals.ctypes.data_as(u64p), 1, bits, 3, lde.ctypes.data_as(u64p), 0) == 0, gpu.lib().p2_last_error()
+    ref = vals.copy()
+    orc.lib().orc_fft(ref.ctypes.data_as(u64p), bits, 1)
+    assert (ref == out).all()
+    ref_lde = np.zeros(8 * n, dtype=np.uint64)
+    orc.lib().orc_lde(vals.ctypes.data_as(u64p), bits, 3, ref_lde.ctypes.data_as(u64p))
+    assert (ref_lde == lde).all()
+
+
 def test_intt_rejects_unsupported_sizes(gpu):
     arr = (C.c_uint64 * 4)()
     assert gpu.lib().p2_gpu_intt(arr, 1, 0, arr, 0) != 0
