@@ -143,9 +143,9 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
     // (slots (inp, out): the LDC transition of each partial poly)
     auto lut_slot = [&](u32 s_, u64 win, u64 wout, u64 wm) {
         for (u32 i = 0; i < 2; i++) {
-            cur[i] = gl::add(gl::mul(cur[i], dD[i]), gl::add(win, gl::mul(dB[i], wout)));
-            const u64 f = gl::sub(dAl[i], gl::add(win, gl::mul(dA[i], wout)));
-            tsum[i] = gl::add(gl::mul(tsum[i], f), gl::mul(wm, tprod[i]));  // sum' = sum*f + mult*prod
+            cur[i] = gl::mul_add(cur[i], dD[i], gl::mul_add_nc(dB[i], wout, win));
+            const u64 f = gl::sub(dAl[i], gl::mul_add(dA[i], wout, win));
+            tsum[i] = gl::mul_add(tsum[i], f, gl::mul_nc(wm, tprod[i]));  // sum' = sum*f + mult*prod
             tprod[i] = gl::mul(tprod[i], f);
         }
         if (++tin == a.lut_deg || s_ + 1 == p2::LUT_SLOTS) {
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
     };
     auto lu_slot = [&](u32 s_, u64 win, u64 wout) {
         for (u32 i = 0; i < 2; i++) {
-            const u64 f = gl::sub(dAl[i], gl::add(win, gl::mul(dA[i], wout)));
-            lsum[i] = gl::add(gl::mul(lsum[i], f), lprod[i]);
+            const u64 f = gl::sub(dAl[i], gl::mul_add(dA[i], wout, win));
+            lsum[i] = gl::mul_add(lsum[i], f, lprod[i]);
             lprod[i] = gl::mul(lprod[i], f);
         }
         if (++lin == lu_deg || s_ + 1 == p2::LU_SLOTS) {
@@ -193,10 +193,13 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
                     const u32 j = 8 * chunk + k;
                     const u64 wv = W[(size_t)j * N], sg = S[(size_t)j * N], kj = a.k_is[j];
                     w8[k] = wv;
-                    num0 = gl::mul(num0, gl::add(gl::add(wv, gl::mul(bx0, kj)), g0));
-                    den0 = gl::mul(den0, gl::add(gl::add(wv, gl::mul(b0, sg)), g0));
-                    num1 = gl::mul(num1, gl::add(gl::add(wv, gl::mul(bx1, kj)), g1));
-                    den1 = gl::mul(den1, gl::add(gl::add(wv, gl::mul(b1, sg)), g1));
+                    // w + gamma once per challenge, the beta term as a fused multiply-add whose (non-canonical) result goes
+                    // straight into the running product: 2 adds + 4 fused ops + 4 products instead of 8 adds + 8 products
+                    const u64 t0 = gl::add(wv, g0), t1 = gl::add(wv, g1);
+                    num0 = gl::mul(num0, gl::mul_add_nc(bx0, kj, t0));
+                    den0 = gl::mul(den0, gl::mul_add_nc(b0, sg, t0));
+                    num1 = gl::mul(num1, gl::mul_add_nc(bx1, kj, t1));
+                    den1 = gl::mul(den1, gl::mul_add_nc(b1, sg, t1));
                 }
             } else {
                 for (u32 j = chunk * a.qdf; j < j1; j++) {
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
                 // ArithmeticGate ops 2*chunk and 2*chunk + 1 occupy exactly these 8 wires: out - (c0 m0 m1 + c1 addend)
                 for (u32 h = 0; h < 2; h++) {
                     const u64 m0 = w8[4 * h], m1 = w8[4 * h + 1], ad = w8[4 * h + 2], o = w8[4 * h + 3];
-                    A.add(idx_gate + 2 * chunk + h, gl::mul(f_arith, gl::sub(o, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1)))));
+                    A.add(idx_gate + 2 * chunk + h, gl::mul(f_arith, gl::sub(o, gl::mul_add(gl::mul_nc(m0, m1), c0, gl::mul_nc(ad, c1)))));
                 }
             }
             for (u32 i = 0; i < 2; i++) {
