@@ -69,7 +69,7 @@ struct AlphaAcc {
 // chunk or the last two of the previous one, which are carried over.  Nothing else changes: every accumulator takes exact
 // integer sums (AlphaAcc), so the order in which the terms arrive does not show in the result.
 template <bool HAS_POSEIDON, bool ONE_WALK = false>
-__global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
+__global__ __launch_bounds__(256, 4) void k_quotient(QuotientArgs a) {
     static_assert(!(HAS_POSEIDON && ONE_WALK), "the one-walk form rides on the ArithmeticGate layout of routed-only circuits");
     const u32 N = a.n << a.rate_bits;
     const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -195,11 +195,17 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientArgs a) {
                     w8[k] = wv;
                     // w + gamma once per challenge, the beta term as a fused multiply-add whose (non-canonical) result goes
                     // straight into the running product: 2 adds + 4 fused ops + 4 products instead of 8 adds + 8 products
-                    const u64 t0 = gl::add(wv, g0), t1 = gl::add(wv, g1);
-                    num0 = gl::mul(num0, gl::mul_add_nc(bx0, kj, t0));
-                    den0 = gl::mul(den0, gl::mul_add_nc(b0, sg, t0));
-                    num1 = gl::mul(num1, gl::mul_add_nc(bx1, kj, t1));
-                    den1 = gl::mul(den1, gl::mul_add_nc(b1, sg, t1));
+                    // (one challenge after the other: with both sums live the kernel spills at its 128-register budget)
+                    {
+                        const u64 t = gl::add(wv, g0);
+                        num0 = gl::mul(num0, gl::mul_add_nc(bx0, kj, t));
+                        den0 = gl::mul(den0, gl::mul_add_nc(b0, sg, t));
+                    }
+                    {
+                        const u64 t = gl::add(wv, g1);
+                        num1 = gl::mul(num1, gl::mul_add_nc(bx1, kj, t));
+                        den1 = gl::mul(den1, gl::mul_add_nc(b1, sg, t));
+                    }
                 }
             } else {
                 for (u32 j = chunk * a.qdf; j < j1; j++) {
