@@ -317,7 +317,7 @@ def main():
         traffic = None
         tj, traffic_source = profile("traffic")
         try:  # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x2 per calibration, WRITE_SIZE), profiles/
-            key = {"hash_leaves": "k_hash_leaves", "lde": "k_ntt_r16<true>", "quotient": "k_quotient<false>"}.get(dom)
+            key = {"hash_leaves": "k_hash_leaves", "lde": "k_ntt_r16<true>", "quotient": "k_quotient<false, true>"}.get(dom)
             if tj and key and L == 1024 and chunk == tj.get("chunk") and args.workload == "aes-gcm":
                 ent = tj["per_launch_avg_bytes"][key]
                 traffic = ent.get("chunk_launches_avg", ent["total"])
@@ -336,7 +336,7 @@ def main():
         vjj, valu_source = profile("valu")
         try:
             vj = vjj["kernels"] if vjj else {}
-            key = {"hash_leaves": "k_hash_leaves", "lde": "k_ntt_r16<true>", "quotient": "k_quotient<false>"}.get(dom)
+            key = {"hash_leaves": "k_hash_leaves", "lde": "k_ntt_r16<true>", "quotient": "k_quotient<false, true>"}.get(dom)
             if key in vj and L == 1024 and args.workload == "aes-gcm" and chunk == 128:
                 e = vj[key]
                 clock = e["clock_GHz"] * 1e9
