@@ -549,7 +549,7 @@ def test_schedule_switches_change_scheduling_not_proofs(gpu, monkeypatch):
     small, st = data.prove_batch(pws[:3])                       # batch <= 16: fused Merkle top
     assert st == [0] * 3 and small == ref[:3]
     for env in ({"P2AES_WITNESS_FUSE": "8"}, {"P2AES_WITNESS_FUSE": "4", "P2AES_MERKLE_TOP": "0"}, {"P2AES_PASS1_RADIX2": "1", "P2AES_PASS1_NOSWIZZLE": "1"},
-                {"P2AES_PASS1_WAVES": "2"}):
+                {"P2AES_PASS1_WAVES": "2", "P2AES_QUOTIENT_TWO_WALKS": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         other = gpu.CircuitData(data.blob)
