@@ -84,6 +84,21 @@ def kernel_bytes(name, info, active_wires=80):
     return None
 
 
+def cpu_quota_cores():
+    """CPU share of this container in cores (cgroup v2 cpu.max, v1 cfs quota), or None when unlimited / unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def load_profile(kind, root=ROOT, tag=None):
     """profiles/<tag>_<kind>.json (written by tools/pmc_traffic.py / pmc_valu.py from rocprofv3 PMC passes) and where it came from.
     The counter files are evidence taken on ONE build: each records the identity of the kernel sources it was measured on
@@ -142,8 +157,8 @@ def main():
                          "batch 1024 over 8 GPUs (--workload elgamal --batch 128), 5 = AES-GCM 64 KiB with the per-GPU share of batch 256 over "
                          "8 GPUs (--plaintext-bytes 65536 --batch 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=32, help="OpenMP threads of the cpu_baseline leg (32 is the measured optimum of the port on the GPU boxes' hosts)")
-    ap.add_argument("--cpu-sample", type=int, default=3, help="proofs timed on the host for cpu_baseline (median, after one warm-up)")
+    ap.add_argument("--cpu-threads", type=int, default=32, help="most OpenMP threads of the cpu_baseline leg (the port stops scaling at 16-32 on the GPU boxes' hosts; a cgroup CPU quota below this lowers it)")
+    ap.add_argument("--cpu-sample", type=int, default=12, help="proofs timed on the host for cpu_baseline (median, after one warm-up)")
     args = ap.parse_args()
 
     if args.config == 4:
@@ -358,13 +373,18 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU baseline is reported at N = 1 only
         import oracle_lib  # the checker, used here only as the reported CPU baseline
         oc = oracle_lib.OracleCircuit(data.blob)
-        # The port does not scale past one socket's worth of threads: on the 2 x 64-core EPYC host of the GPU boxes one proof
-        # takes 3.1 s on 128 threads, 2.2 s on 64, 1.9 s on 32 and 16, 3.4 s on 8 (tools/orc_scale.py).  Use the best: 32.
+        # The port stops scaling at 16-32 threads on the 2 x 64-core EPYC 9575F host of the GPU boxes: one proof takes 1.09 s on
+        # 128 threads, 0.62 s on 64, 0.44 s on 32 and on 16, 0.68 s on 8, 4.1 s on one (tools/orc_scale.py fast,
+        # profiles/r03_cpu_baseline_scaling.log).  Use the best: 32, or the container's CPU quota when that is lower.
         all_cores = oracle_lib.lib().orc_num_threads()
-        oracle_lib.lib().orc_set_num_threads(min(all_cores, args.cpu_threads))
-        # the oracle's faster form of its own hash (sparse partial rounds, lazy reduction; oracle/oracle_poseidon_sparse.h, held to
-        # the textbook permutation by tests/test_oracle_kat.py): the baseline should not be handicapped by a 30-round loop
+        quota = cpu_quota_cores()  # the GPU boxes hand a container a share of the host's cores: threads beyond it only add switches
+        cores = max(1, min(all_cores, args.cpu_threads, int(quota + 0.999) if quota else all_cores))
+        oracle_lib.lib().orc_set_num_threads(cores)
+        # the oracle's faster form of its own hash (sparse partial rounds, lazy reduction, one leaf per SIMD lane:
+        # oracle/oracle_poseidon_sparse.h, oracle_poseidon_simd.h; held to the textbook permutation by tests/test_oracle_kat.py):
+        # the baseline should not be handicapped by a 30-round scalar loop
         oracle_lib.lib().orc_set_fast_hash(1)
+        lanes = oracle_lib.lib().orc_set_simd_lanes(8)  # 8 = AVX-512, 4 = AVX2, 1 = scalar: whatever the host has
         st, ref = oc.prove(pws[0].map)  # warm-up (page faults, OpenMP team start-up)
         times = []
         for i in range(args.cpu_sample):
@@ -376,7 +396,6 @@ def main():
         got = bytes(proofs[: args.cpu_sample * pb].cpu().numpy().tobytes())
         assert got[(args.cpu_sample - 1) * pb: args.cpu_sample * pb] == ref, "GPU proof differs from the oracle's"
         stages = {k: round(v, 4) for k, v in oracle_lib.OracleCircuit.last_stage_seconds().items()}  # of the last proof timed
-        cores = min(all_cores, args.cpu_threads)
         # thread scaling: ONE proof on one thread (BASELINE.md asks for the core count used and how the port scales)
         oracle_lib.lib().orc_set_num_threads(1)
         t1 = time.perf_counter()
@@ -386,7 +405,8 @@ def main():
         oracle_lib.lib().orc_set_num_threads(cores)
         oracle_lib.lib().orc_set_fast_hash(0)
         cpu_baseline = {"value": round(args.cpu_sample / cdt, 4), "unit": "proofs/s", "cores": cores,
-                        "kind": "port", "sample": "median of %d proofs after 1 warm-up, same workload (%s; C++ restatement with its sparse-partial-round Poseidon, OpenMP; not the Rust reference)" % (args.cpu_sample, label.split(" (")[0]),
+                        "kind": "port", "sample": "median of %d proofs after 1 warm-up, same workload (%s; C++ restatement with its fast hash -- sparse partial rounds, %d leaves per SIMD call -- and OpenMP; not the Rust reference)" % (args.cpu_sample, label.split(" (")[0], lanes),
+                        "simd_lanes": lanes, "cpu_quota_cores": quota,
                         "stage_seconds": stages, "single_thread": {"value": round(1.0 / one, 4), "unit": "proofs/s", "stage_seconds": stages1,
                                                                    "speedup_at_cores": round(one * args.cpu_sample / cdt, 2), "host_threads_available": all_cores}}
 

@@ -178,4 +178,28 @@ void orc_set_num_threads(int t) { omp_set_num_threads(t); }
 // textbook 30-round loop (the default, and what the parity tests use).  Process-wide.
 void orc_set_fast_hash(int on) { g_sparse_poseidon = on != 0; }
 void orc_poseidon_sparse(uint64_t* st) { poseidon_permute_sparse(st); }
+// most SIMD lanes the fast hash may use (8, 4 or 1); returns the lanes it will use on this host
+// test hooks: the lane arithmetic of the SIMD hash on `lanes` arbitrary words per operand (out: 6 x lanes words, see
+// PoseidonLanes::test_arith); returns 0 when the host cannot run that many lanes.  Hashing of rows with the fast hash.
+int orc_simd_test_arith(int lanes, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out) {
+    const int keep = g_simd_cap;
+    g_simd_cap = 8;
+    const int host = simd_lanes();
+    g_simd_cap = keep;
+#if defined(__x86_64__) && !defined(ORC_NO_SIMD)
+    if (lanes == 8 && host >= 8) return simd512_test_arith(a, b, c, out), 1;
+    if (lanes == 4 && host >= 4) return simd256_test_arith(a, b, c, out), 1;
+#endif
+    (void)host;
+    return 0;
+}
+void orc_batch_inverse(uint64_t* v, size_t n) {
+    std::vector<u64> t(v, v + n);
+    batch_inverse_parallel(t);
+    memcpy(v, t.data(), n * 8);
+}
+int orc_set_simd_lanes(int lanes) {
+    g_simd_cap = lanes;
+    return simd_lanes();
+}
 }

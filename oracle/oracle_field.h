@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <mutex>
 #include <stdexcept>
 #include <vector>
 
@@ -32,20 +33,26 @@ typedef unsigned __int128 u128;
 static const u64 MODULUS = 18446744069414584321ull;
 
 static inline u64 fred(u128 x) {
-    // x = lo + 2^64*(hl + 2^32*hh);  2^64 = 2^32-1, 2^96 = -1  (mod p)
+    // x = lo + 2^64*(hl + 2^32*hh);  2^64 = 2^32-1, 2^96 = -1  (mod p):  x = lo - hh + hl*(2^32-1).
+    // Written without data-dependent branches (the wrap tests are coin flips on random data): a borrow of 2^64 is paid
+    // back as -(2^32-1), a carry as +(2^32-1); neither can wrap twice (after a borrow t0 >= 2^64-2^32; after a carry
+    // r < hl*(2^32-1) <= 2^64-2^33+1).  The result of the folds is some representative below 2^64 < 2p.
+    const u64 E = 0xffffffffull;
     u64 lo = (u64)x, hi = (u64)(x >> 64);
-    u64 hh = hi >> 32, hl = hi & 0xffffffffull;
-    __int128 t = (__int128)lo + (__int128)((u128)hl * 0xffffffffull) - (__int128)hh;
-    if (t < 0) t += MODULUS;
-    while (t >= (__int128)MODULUS) t -= MODULUS;
-    return (u64)t;
+    u64 hh = hi >> 32, hl = hi & E;
+    u64 t0 = lo - hh;
+    t0 -= (0 - (u64)(lo < hh)) & E;
+    u64 t1 = (hl << 32) - hl;
+    u64 r = t0 + t1;
+    r += (0 - (u64)(r < t1)) & E;
+    return r >= MODULUS ? r - MODULUS : r;
 }
+// canonical in, canonical out; no data-dependent branches (sum >= p and a < b are coin flips on random data)
 static inline u64 fadd(u64 a, u64 b) {
-    u128 s = (u128)a + b;
-    if (s >= MODULUS) s -= MODULUS;
-    return (u64)s;
+    const u64 s = a + b, t = s - MODULUS;
+    return ((s < a) | (s >= MODULUS)) ? t : s;
 }
-static inline u64 fsub(u64 a, u64 b) { return a >= b ? a - b : (u64)((u128)a + MODULUS - b); }
+static inline u64 fsub(u64 a, u64 b) { return a - b + ((0 - (u64)(a < b)) & MODULUS); }
 static inline u64 fneg(u64 a) { return a ? MODULUS - a : 0; }
 static inline u64 fmul(u64 a, u64 b) { return fred((u128)a * b); }
 static inline u64 fpow(u64 b, u64 e) {
@@ -111,6 +118,9 @@ static inline u64 pow7(u64 x) {
 // oracle_poseidon_sparse.h (orc_set_fast_hash): the same function, held to this one by tests/test_oracle_kat.py
 static bool g_sparse_poseidon = false;
 static inline void poseidon_permute_sparse(u64 st[12]);
+struct Digest;
+static inline void hash_rows_fast(const u64* rows, size_t first, size_t count, size_t width, Digest* out);
+static inline void compress_level_fast(const Digest* src, Digest* dst, size_t first, size_t count);
 static inline void poseidon_permute(u64 st[12]) {
     if (g_sparse_poseidon) return poseidon_permute_sparse(st);
     for (int round = 0; round < 30; round++) {
@@ -197,15 +207,29 @@ static inline MerkleTree build_merkle(const u64* leaves, size_t num_leaves, size
     while (((size_t)1 << t.height) < num_leaves) t.height++;
     t.cap_height = cap_height < t.height ? cap_height : t.height;
     t.levels.emplace_back(num_leaves);
+    const size_t BLK = 64;  // rows per work item (a multiple of every lane count of the fast hash)
+    const bool fast = g_sparse_poseidon && width > 4;
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < num_leaves; i++) t.levels[0][i] = hash_or_noop(leaves + i * width, width);
+    for (size_t i0 = 0; i0 < num_leaves; i0 += BLK) {
+        const size_t cnt = num_leaves - i0 < BLK ? num_leaves - i0 : BLK;
+        if (fast)
+            hash_rows_fast(leaves, i0, cnt, width, t.levels[0].data());
+        else
+            for (size_t i = i0; i < i0 + cnt; i++) t.levels[0][i] = hash_or_noop(leaves + i * width, width);
+    }
     for (int l = 0; l < t.height - t.cap_height; l++) {
         size_t m = t.levels[l].size() / 2;
         t.levels.emplace_back(m);
         auto& src = t.levels[l];
         auto& dst = t.levels[l + 1];
 #pragma omp parallel for schedule(static) if (m > 256)
-        for (size_t i = 0; i < m; i++) dst[i] = compress(src[2 * i], src[2 * i + 1]);
+        for (size_t i0 = 0; i0 < m; i0 += BLK) {
+            const size_t cnt = m - i0 < BLK ? m - i0 : BLK;
+            if (g_sparse_poseidon)
+                compress_level_fast(src.data(), dst.data(), i0, cnt);
+            else
+                for (size_t i = i0; i < i0 + cnt; i++) dst[i] = compress(src[2 * i], src[2 * i + 1]);
+        }
     }
     return t;
 }
@@ -282,6 +306,52 @@ static inline void fft_inplace(u64* a, int bits, bool inverse) {
         u64 ni = finv((u64)n % MODULUS);
         for (size_t i = 0; i < n; i++) a[i] = fmul(a[i], ni);
     }
+}
+// w^j for j < 2^(bits-1), w = root_of_unity(bits): built once per size
+static inline const std::vector<u64>& forward_twiddles(int bits) {
+    static std::vector<u64> tables[33];
+    static std::mutex guard;
+    std::lock_guard<std::mutex> lock(guard);
+    std::vector<u64>& t = tables[bits];
+    if (t.empty()) {
+        t.resize(bits ? (size_t)1 << (bits - 1) : 1);
+        const u64 w = root_of_unity(bits);
+        u64 x = 1;
+        for (auto& v : t) {
+            v = x;
+            x = fmul(x, w);
+        }
+    }
+    return t;
+}
+// the same transform as fft_inplace(a, bits, false) with the output left in bit-reversed order (position rev(k) holds X[k]):
+// decimation in frequency, no permutation pass.  The low-degree extensions are stored in that order.
+static inline void fft_bitrev_out(u64* a, int bits) {
+    const size_t n = (size_t)1 << bits;
+    const std::vector<u64>& tw = forward_twiddles(bits);
+    for (size_t half = n >> 1, step = 1; half >= 1; half >>= 1, step <<= 1)
+        for (size_t k = 0; k < n; k += 2 * half)
+            for (size_t j = 0; j < half; j++) {
+                const u64 u = a[k + j], v = a[k + j + half];
+                a[k + j] = fadd(u, v);
+                a[k + j + half] = fmul(fsub(u, v), tw[j * step]);
+            }
+}
+// out[rev(k)] = value of `coeffs` (zero-padded to 2^bits) at shift * w^k;  shift_pows[i] = shift^i
+static inline void coset_fft_bitrev_out(const std::vector<u64>& coeffs, const std::vector<u64>& shift_pows, int bits, u64* out) {
+    const size_t n = (size_t)1 << bits;
+    for (size_t i = 0; i < coeffs.size(); i++) out[i] = fmul(coeffs[i], shift_pows[i]);
+    for (size_t i = coeffs.size(); i < n; i++) out[i] = 0;
+    fft_bitrev_out(out, bits);
+}
+static inline std::vector<u64> powers_of(u64 x, size_t count) {
+    std::vector<u64> p(count);
+    u64 s = 1;
+    for (auto& v : p) {
+        v = s;
+        s = fmul(s, x);
+    }
+    return p;
 }
 // values of the polynomial `coeffs` (zero-padded to 2^bits) on shift*<w>, natural order
 static inline std::vector<u64> coset_fft(const std::vector<u64>& coeffs, int bits, u64 shift) {

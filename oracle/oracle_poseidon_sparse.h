@@ -108,12 +108,13 @@ static inline const SparsePoseidon& sparse_poseidon() {
 //   2^64 = 2^32 - 1 and 2^96 = -1 (mod p):  lo + 2^64 (hl + 2^32 hh) = lo - hh + hl (2^32 - 1), folded with wrap corrections
 static const u64 EPS = 0xFFFFFFFFull;
 static inline u64 lred(u128 x) {
+    // branch-free: the two wrap tests are coin flips on random data, and a mispredicted branch costs more than the whole fold
     const u64 lo = (u64)x, hi = (u64)(x >> 64), hh = hi >> 32, hl = hi & EPS;
     u64 t0 = lo - hh;
-    if (lo < hh) t0 -= EPS;           // borrowed 2^64 = EPS (mod p); cannot underflow again: t0 >= 2^64 - 2^32 after a borrow
-    const u64 t1 = hl * EPS;          // < 2^64
+    t0 -= (0 - (u64)(lo < hh)) & EPS;  // borrowed 2^64 = EPS (mod p); cannot underflow again: t0 >= 2^64 - 2^32 after a borrow
+    const u64 t1 = (hl << 32) - hl;    // hl * EPS < 2^64
     u64 r = t0 + t1;
-    if (r < t1) r += EPS;             // wrapped: + 2^64 = + EPS; cannot wrap again
+    r += (0 - (u64)(r < t1)) & EPS;    // wrapped: + 2^64 = + EPS; cannot wrap again
     return r;
 }
 static inline u64 lmul(u64 a, u64 b) { return lred((u128)a * b); }
@@ -123,7 +124,7 @@ static inline u64 lpow7(u64 x) {
 }
 static inline u64 ladd(u64 a, u64 c) {  // a arbitrary, c canonical: some representative of a + c
     u64 r = a + c;
-    if (r < c) r += EPS;              // r < c <= p - 1 after the wrap, so + EPS cannot wrap
+    r += (0 - (u64)(r < c)) & EPS;    // r < c <= p - 1 after the wrap, so + EPS cannot wrap
     return r;
 }
 static inline u64 lcanon(u64 a) { return a >= MODULUS ? a - MODULUS : a; }
@@ -179,6 +180,58 @@ static inline void poseidon_permute_sparse(u64 st[12]) {
     full_round(st, ROUND_CONSTANTS + 12 * 26, S.TAIL);
     for (int r = 27; r < 30; r++) full_round(st, ROUND_CONSTANTS + 12 * r, nullptr);
     for (int i = 0; i < 12; i++) st[i] = lcanon(st[i]);
+}
+
+// ---- lane-parallel forms (oracle_poseidon_simd.h, instantiated in oracle_simd_avx512.cpp / oracle_simd_avx2.cpp)
+void simd512_hash_rows(const SparsePoseidon* S, const u64* rows, size_t row_stride, size_t width, Digest* out);
+void simd512_compress_pairs(const SparsePoseidon* S, const Digest* src, Digest* dst);
+void simd256_hash_rows(const SparsePoseidon* S, const u64* rows, size_t row_stride, size_t width, Digest* out);
+void simd256_compress_pairs(const SparsePoseidon* S, const Digest* src, Digest* dst);
+void simd512_test_arith(const u64* a, const u64* b, const u64* c, u64* out);
+void simd256_test_arith(const u64* a, const u64* b, const u64* c, u64* out);
+// lanes the host can run: 8 (AVX-512 F + DQ), 4 (AVX2) or 1; g_simd_cap (orc_set_simd_lanes) lowers it for the tests
+static int g_simd_cap = 8;
+static inline int simd_lanes() {
+#if defined(__x86_64__) && !defined(ORC_NO_SIMD)
+    static const int host = [] {
+        __builtin_cpu_init();
+        if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq")) return 8;
+        if (__builtin_cpu_supports("avx2")) return 4;
+        return 1;
+    }();
+    const int l = host < g_simd_cap ? host : g_simd_cap;
+    return l >= 8 ? 8 : l >= 4 ? 4 : 1;
+#else
+    return 1;
+#endif
+}
+// hash_no_pad of rows [0, count) of `width` > 4 words each (row-major), digests to out[]: SIMD blocks, scalar tail
+static inline void hash_rows_fast(const u64* rows, size_t first, size_t count, size_t width, Digest* out) {
+    const SparsePoseidon& S = sparse_poseidon();
+    const size_t lanes = (size_t)simd_lanes();
+    size_t i = first;
+    const size_t end = first + count;
+#if defined(__x86_64__) && !defined(ORC_NO_SIMD)
+    if (lanes == 8)
+        for (; i + 8 <= end; i += 8) simd512_hash_rows(&S, rows + i * width, width, width, out + i);
+    else if (lanes == 4)
+        for (; i + 4 <= end; i += 4) simd256_hash_rows(&S, rows + i * width, width, width, out + i);
+#endif
+    for (; i < end; i++) out[i] = hash_no_pad(rows + i * width, width);
+}
+// dst[i] = compress(src[2 i], src[2 i + 1]) for i in [first, first + count)
+static inline void compress_level_fast(const Digest* src, Digest* dst, size_t first, size_t count) {
+    const SparsePoseidon& S = sparse_poseidon();
+    const size_t lanes = (size_t)simd_lanes();
+    size_t i = first;
+    const size_t end = first + count;
+#if defined(__x86_64__) && !defined(ORC_NO_SIMD)
+    if (lanes == 8)
+        for (; i + 8 <= end; i += 8) simd512_compress_pairs(&S, src + 2 * i, dst + i);
+    else if (lanes == 4)
+        for (; i + 4 <= end; i += 4) simd256_compress_pairs(&S, src + 2 * i, dst + i);
+#endif
+    for (; i < end; i++) dst[i] = compress(src[2 * i], src[2 * i + 1]);
 }
 
 }  // namespace orc

@@ -147,10 +147,19 @@ static inline void commit_from_coeffs(const OCircuit& C, Batch& b, int oracle_in
     size_t salt = (C.cfg.zero_knowledge && oracle_index > 0) ? 4 : 0;
     b.width = cols + salt;
     b.lde.assign(N * b.width, 0);
+    {
+        // column by column into a column-major scratch (the transform leaves position rev(k) = the storage order), then
+        // transposed in blocks of rows so that every cache line of the row-major table is written once
+        std::vector<u64> by_col(cols * N);
+        const std::vector<u64> shift_pows = powers_of(GENERATOR, n);
+        forward_twiddles(C.lde_bits);
 #pragma omp parallel for schedule(dynamic, 1)
-    for (size_t c = 0; c < cols; c++) {
-        std::vector<u64> v = coset_fft(b.coeffs[c], C.lde_bits, GENERATOR);
-        for (size_t i = 0; i < N; i++) b.lde[rev_bits(i, C.lde_bits) * b.width + c] = v[i];
+        for (size_t c = 0; c < cols; c++) coset_fft_bitrev_out(b.coeffs[c], shift_pows, C.lde_bits, &by_col[c * N]);
+        const size_t RB = 64;
+#pragma omp parallel for schedule(static)
+        for (size_t r0 = 0; r0 < N; r0 += RB)
+            for (size_t c = 0; c < cols; c++)
+                for (size_t r = r0; r < r0 + RB && r < N; r++) b.lde[r * b.width + c] = by_col[c * N + r];
     }
     if (salt) {
         ZkStream zs(C.zk_key, C.zk_proof, 3 + oracle_index);
@@ -526,6 +535,28 @@ static inline void eval_vanishing(const OCircuit& C, const Challenges& ch, u64 x
     }
 }
 
+// v[i] <- 1 / v[i] for every i (0 stays 0, as finv(0) = 0): one inversion per block of 1024 (Montgomery's trick), blocks in parallel
+static inline void batch_inverse_parallel(std::vector<u64>& v) {
+    const size_t BLK = 1024, count = v.size();
+#pragma omp parallel for schedule(static)
+    for (size_t b0 = 0; b0 < count; b0 += BLK) {
+        const size_t m = std::min(BLK, count - b0);
+        u64 prefix[BLK];
+        u64 acc = 1;
+        for (size_t k = 0; k < m; k++) {
+            prefix[k] = acc;  // product of the non-zero entries before k
+            if (v[b0 + k]) acc = fmul(acc, v[b0 + k]);
+        }
+        u64 inv = finv(acc);
+        for (size_t k = m; k-- > 0;) {
+            const u64 x = v[b0 + k];
+            if (!x) continue;
+            v[b0 + k] = fmul(inv, prefix[k]);
+            inv = fmul(inv, x);
+        }
+    }
+}
+
 static inline X2 eval_poly_ext(const std::vector<u64>& coeffs, X2 z) {
     X2 acc = x2(0);
     for (size_t i = coeffs.size(); i-- > 0;) acc = acc * z + x2(coeffs[i]);
@@ -610,7 +641,8 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
             x = fmul(x, w);
         }
         for (size_t i = 0; i < NC; i++) {
-            std::vector<u64> q((npp + 1) * n);
+            // quotient num / den per (row, chunk): the denominators are inverted together (batch_inverse), block by block
+            std::vector<u64> q((npp + 1) * n), dens((npp + 1) * n);
 #pragma omp parallel for schedule(static)
             for (size_t row = 0; row < n; row++) {
                 for (size_t chunk = 0; chunk <= npp; chunk++) {
@@ -620,9 +652,13 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
                         num = fmul(num, fadd(fadd(wv, fmul(ch.betas[i], fmul(C.k_is[j], subgroup[row]))), ch.gammas[i]));
                         den = fmul(den, fadd(fadd(wv, fmul(ch.betas[i], C.sigmas[j * n + row])), ch.gammas[i]));
                     }
-                    q[chunk * n + row] = fmul(num, finv(den));
+                    q[chunk * n + row] = num;
+                    dens[chunk * n + row] = den;
                 }
             }
+            batch_inverse_parallel(dens);
+#pragma omp parallel for schedule(static)
+            for (size_t k = 0; k < q.size(); k++) q[k] = fmul(q[k], dens[k]);
             u64 z = 1;
             for (size_t row = 0; row < n; row++) {
                 zcols[i][row] = z;
@@ -641,16 +677,31 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
         auto col = [&](size_t p) -> std::vector<u64>& { return zcols[NC * (1 + npp) + i * nlp + p]; };
         const size_t lu_deg = qdf - 1, lut_deg = C.lut_degree();
         for (auto lr : C.lookup_rows) {
+            // 1 / (delta_2 - combo) of every (row, slot entry) first, all at once; the running sums below are serial
+            const size_t lut_rows = lr.first_lut + 1 - lr.last_lut, lu_rows = lr.last_lut - lr.last_lu;
+            std::vector<u64> inv_lut(lut_rows * 26), inv_lu(lu_rows * 40);
+#pragma omp parallel for schedule(static)
+            for (size_t k = 0; k < lut_rows; k++)
+                for (size_t s = 0; s < 26; s++) {
+                    const size_t row = lr.last_lut + k;
+                    inv_lut[k * 26 + s] = fsub(d[2], fadd(wires[3 * s][row], fmul(d[0], wires[3 * s + 1][row])));
+                }
+#pragma omp parallel for schedule(static)
+            for (size_t k = 0; k < lu_rows; k++)
+                for (size_t s = 0; s < 40; s++) {
+                    const size_t row = lr.last_lu + k;
+                    inv_lu[k * 40 + s] = fsub(d[2], fadd(wires[2 * s][row], fmul(d[0], wires[2 * s + 1][row])));
+                }
+            batch_inverse_parallel(inv_lut);
+            batch_inverse_parallel(inv_lu);
             for (size_t row = lr.first_lut + 1; row-- > lr.last_lut;) {
                 u64 re = col(0)[row + 1];
                 for (int s = 0; s < 26; s++) re = fadd(fmul(re, d[3]), fadd(wires[3 * s][row], fmul(d[1], wires[3 * s + 1][row])));
                 col(0)[row] = re;
                 for (size_t slot = 0; slot < nsldc; slot++) {
                     u64 acc = slot ? col(slot)[row] : col(nsldc)[row + 1];
-                    for (size_t s = slot * lut_deg; s < std::min<size_t>((slot + 1) * lut_deg, 26); s++) {
-                        u64 combo = fadd(wires[3 * s][row], fmul(d[0], wires[3 * s + 1][row]));
-                        acc = fadd(acc, fmul(wires[3 * s + 2][row], finv(fsub(d[2], combo))));
-                    }
+                    for (size_t s = slot * lut_deg; s < std::min<size_t>((slot + 1) * lut_deg, 26); s++)
+                        acc = fadd(acc, fmul(wires[3 * s + 2][row], inv_lut[(row - lr.last_lut) * 26 + s]));
                     col(slot + 1)[row] = acc;
                 }
             }
@@ -658,10 +709,7 @@ static inline int prove(const OCircuit& C, const u64* in_targets, const u64* in_
                 for (size_t slot = 0; slot < nsldc; slot++) {
                     u64 prev = slot ? col(slot)[row] : col(nsldc)[row + 1];
                     u64 sum = 0;
-                    for (size_t s = slot * lu_deg; s < std::min<size_t>((slot + 1) * lu_deg, 40); s++) {
-                        u64 combo = fadd(wires[2 * s][row], fmul(d[0], wires[2 * s + 1][row]));
-                        sum = fadd(sum, finv(fsub(d[2], combo)));
-                    }
+                    for (size_t s = slot * lu_deg; s < std::min<size_t>((slot + 1) * lu_deg, 40); s++) sum = fadd(sum, inv_lu[(row - lr.last_lu) * 40 + s]);
                     col(slot + 1)[row] = fsub(prev, sum);
                 }
             }

@@ -53,6 +53,9 @@ def lib():
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_fast_hash.argtypes = [C.c_int]
         L.orc_poseidon_sparse.argtypes = [u64p]
+        L.orc_set_simd_lanes.restype, L.orc_set_simd_lanes.argtypes = C.c_int, [C.c_int]
+        L.orc_simd_test_arith.restype, L.orc_simd_test_arith.argtypes = C.c_int, [C.c_int, u64p, u64p, u64p, u64p]
+        L.orc_batch_inverse.argtypes = [u64p, sz]
         _lib = L
     return _lib
 

@@ -5,6 +5,8 @@ import json
 import os
 import random
 
+import pytest
+
 P = 0xFFFFFFFF00000001
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "aes_kat.json")))
 
@@ -48,10 +50,81 @@ def test_sparse_partial_rounds_are_the_same_permutation(orc, pkg):
     st, ref = oc.prove(pws[0].map)
     try:
         L.orc_set_fast_hash(1)
-        st2, fast = orc.OracleCircuit(data.blob).prove(pws[0].map)
+        for lanes in (8, 4, 1):  # AVX-512, AVX2 (where the host has them) and scalar forms of the fast hash
+            L.orc_set_simd_lanes(lanes)
+            st2, fast = orc.OracleCircuit(data.blob).prove(pws[0].map)
+            assert st == 0 and st2 == 0 and fast == ref, lanes
     finally:
         L.orc_set_fast_hash(0)
-    assert st == 0 and st2 == 0 and fast == ref
+        L.orc_set_simd_lanes(8)
+
+
+EDGE_WORDS = [0, 1, 2, 0xFFFFFFFE, 0xFFFFFFFF, 1 << 32, (1 << 32) + 1, (1 << 33) - 1, (1 << 63) - 1, 1 << 63, P - 2, P - 1, P, P + 1,
+              (1 << 64) - (1 << 32), (1 << 64) - 2, (1 << 64) - 1, 0xFFFFFFFF00000000, 0x00000000FFFFFFFF, 0xFFFFFFFEFFFFFFFF]
+
+
+@pytest.mark.parametrize("lanes", [8, 4])
+def test_simd_lane_arithmetic_on_arbitrary_words(orc, lanes):
+    """oracle/oracle_poseidon_simd.h works on ARBITRARY 64-bit representatives and pays every wrap of 2^64 back at once; the
+    carries that decide it are 2^-32 events on random data, so the operations are held to big-integer arithmetic on every triple
+    of edge words (around 0, 2^32, 2^63, p, 2^64) and on random words."""
+    L, r = orc.lib(), random.Random(11)
+    triples = [(a, b, c) for a in EDGE_WORDS for b in EDGE_WORDS for c in EDGE_WORDS]
+    triples += [(r.getrandbits(64), r.getrandbits(64), r.getrandbits(64)) for _ in range(4000)]
+    while len(triples) % lanes:
+        triples.append((0, 0, 0))
+    ran = False
+    for k in range(0, len(triples), lanes):
+        chunk = triples[k:k + lanes]
+        a, b, c = ((C.c_uint64 * lanes)(*[t[j] for t in chunk]) for j in range(3))
+        out = (C.c_uint64 * (6 * lanes))()
+        if not L.orc_simd_test_arith(lanes, a, b, c, out):
+            pytest.skip("host CPU cannot run %d lanes" % lanes)
+        ran = True
+        for l, (x, y, z) in enumerate(chunk):
+            want = [x * y % P, x * x % P, (x * y + z) % P, (x * y + y * z + z * x) % P, pow(x, 7, P), (x + chunk[0][2] % P) % P]
+            got = [out[j * lanes + l] for j in range(6)]
+            assert got == want, (hex(x), hex(y), hex(z), got, want)
+    assert ran
+
+
+@pytest.mark.parametrize("lanes", [8, 4, 1])
+def test_simd_hash_is_the_textbook_hash(orc, lanes):
+    """Merkle caps through the lane-parallel sparse Poseidon (the cpu_baseline leg's hash) equal the textbook ones: leaf widths on
+    both sides of the rate (5, 8, 9, 16, 17, 135: one to seventeen permutations per leaf, short last block), leaf counts that
+    leave a scalar tail or none, extreme words in the leaves; then a whole proof."""
+    L, r = orc.lib(), random.Random(5 + lanes)
+    cases = [(64, 5), (64, 8), (64, 9), (128, 16), (32, 17), (256, 135), (16, 4), (8, 3), (2, 135), (4, 9)]
+    try:
+        for leaves, width in cases:
+            words = [r.choice(EDGE_WORDS[:12]) if r.random() < 0.2 else r.randrange(P) for _ in range(leaves * width)]
+            buf = (C.c_uint64 * len(words))(*words)
+            caps = []
+            for fast in (0, 1):
+                L.orc_set_fast_hash(fast)
+                got = L.orc_set_simd_lanes(lanes)
+                if fast and lanes > 1 and got != lanes:
+                    pytest.skip("host CPU cannot run %d lanes" % lanes)
+                out = (C.c_uint64 * (4 * 16))()
+                n = L.orc_merkle_cap(buf, leaves, width, 2, out)
+                caps.append(list(out)[: 4 * n])
+            assert caps[0] == caps[1], (leaves, width)
+    finally:
+        L.orc_set_fast_hash(0)
+        L.orc_set_simd_lanes(8)
+
+
+def test_batch_inverse_is_elementwise_inverse(orc):
+    """One inversion per block (the permutation and lookup stages of the oracle): equal to finv element by element, zeros stay
+    zero (finv(0) = 0), block boundaries (1024) and sizes 0, 1 covered."""
+    L, r = orc.lib(), random.Random(3)
+    for n in (0, 1, 2, 1023, 1024, 1025, 5000):
+        v = [0 if r.random() < 0.05 else r.randrange(P) for _ in range(n)]
+        if n > 2:
+            v[0], v[-1] = 0, P - 1
+        buf = (C.c_uint64 * max(n, 1))(*v)
+        L.orc_batch_inverse(buf, n)
+        assert list(buf)[:n] == [pow(x, P - 2, P) for x in v]
 
 
 def test_poseidon_constants_rederive():
