@@ -137,6 +137,8 @@ void orc_two_to_one(const uint64_t* l, const uint64_t* r, uint64_t* out4) {
     memcpy(out4, d.e, 32);
 }
 void orc_fft(uint64_t* a, int bits, int inverse) { fft_inplace(a, bits, inverse != 0); }
+// the transform the commitments use: forward, output in bit-reversed order (SIMD butterflies when the fast switch is on)
+void orc_fft_bitrev_out(uint64_t* a, int bits) { fft_bitrev_out(a, bits); }
 // LDE of one polynomial: coeffs[n] -> values on g*<w_{n<<rate}> written in BIT-REVERSED index order
 void orc_lde(const uint64_t* coeffs, int bits, int rate_bits, uint64_t* out) {
     std::vector<u64> c(coeffs, coeffs + ((size_t)1 << bits));

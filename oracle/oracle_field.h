@@ -324,18 +324,53 @@ static inline const std::vector<u64>& forward_twiddles(int bits) {
     }
     return t;
 }
+// per stage of the decimation-in-frequency transform (half = 2^(bits-1-s)): its twiddles w^(j * 2^s), j < half, contiguous
+static inline const std::vector<std::vector<u64>>& forward_stage_twiddles(int bits) {
+    static std::vector<std::vector<u64>> tables[33];
+    const std::vector<u64>& tw = forward_twiddles(bits);
+    static std::mutex guard;
+    std::lock_guard<std::mutex> lock(guard);
+    std::vector<std::vector<u64>>& t = tables[bits];
+    if (t.empty() && bits) {
+        t.resize(bits);
+        for (int s = 0; s < bits; s++) {
+            const size_t half = (size_t)1 << (bits - 1 - s), step = (size_t)1 << s;
+            t[s].resize(half);
+            for (size_t j = 0; j < half; j++) t[s][j] = tw[j * step];
+        }
+    }
+    return t;
+}
+void simd512_dif_stage(u64* a, size_t n, size_t half, const u64* tw);
+void simd256_dif_stage(u64* a, size_t n, size_t half, const u64* tw);
+static inline int simd_lanes();
 // the same transform as fft_inplace(a, bits, false) with the output left in bit-reversed order (position rev(k) holds X[k]):
-// decimation in frequency, no permutation pass.  The low-degree extensions are stored in that order.
+// decimation in frequency, no permutation pass.  The low-degree extensions are stored in that order.  With the fast switch of
+// the cpu_baseline leg on, stages wide enough run eight (AVX-512) or four (AVX2) butterflies per instruction.
 static inline void fft_bitrev_out(u64* a, int bits) {
     const size_t n = (size_t)1 << bits;
-    const std::vector<u64>& tw = forward_twiddles(bits);
-    for (size_t half = n >> 1, step = 1; half >= 1; half >>= 1, step <<= 1)
+    const std::vector<std::vector<u64>>& stw = forward_stage_twiddles(bits);
+    const size_t lanes = g_sparse_poseidon ? (size_t)simd_lanes() : 1;
+    int s = 0;
+    for (size_t half = n >> 1; half >= 1; half >>= 1, s++) {
+        const u64* tw = stw[s].data();
+#if defined(__x86_64__) && !defined(ORC_NO_SIMD)
+        if (lanes == 8 && half >= 8) {
+            simd512_dif_stage(a, n, half, tw);
+            continue;
+        }
+        if (lanes == 4 && half >= 4) {
+            simd256_dif_stage(a, n, half, tw);
+            continue;
+        }
+#endif
         for (size_t k = 0; k < n; k += 2 * half)
             for (size_t j = 0; j < half; j++) {
                 const u64 u = a[k + j], v = a[k + j + half];
                 a[k + j] = fadd(u, v);
-                a[k + j + half] = fmul(fsub(u, v), tw[j * step]);
+                a[k + j + half] = fmul(fsub(u, v), tw[j]);
             }
+    }
 }
 // out[rev(k)] = value of `coeffs` (zero-padded to 2^bits) at shift * w^k;  shift_pows[i] = shift^i
 static inline void coset_fft_bitrev_out(const std::vector<u64>& coeffs, const std::vector<u64>& shift_pows, int bits, u64* out) {

@@ -165,6 +165,21 @@ struct PoseidonLanes {
         for (int r = 27; r < 30; r++) full_round(st, ROUND_CONSTANTS + 12 * r, nullptr);
         for (int i = 0; i < 12; i++) st[i] = canon(st[i]);
     }
+    // ---- canonical-in, canonical-out butterflies for the transform of the low-degree extension (fft_bitrev_out)
+    static inline V cadd(V a, V b) {
+        const V s = vadd(a, b);
+        return canon(vadd_if_lt(s, s, a, V::set1(E)));  // wrapped: a + b - 2^64 < 2^64 - 2^33, so + (2^32 - 1) stays below 2^64
+    }
+    static inline V csub(V a, V b) { return vsub_if_lt(vsub(a, b), a, b, V::set1(E)); }  // a < b: + p = - (2^32 - 1) mod 2^64
+    // one decimation-in-frequency stage with half >= V::W: pairs (k + j, k + j + half), twiddle tw[j] (contiguous per stage)
+    static inline void dif_stage(u64* a, size_t n, size_t half, const u64* tw) {
+        for (size_t k = 0; k < n; k += 2 * half)
+            for (size_t j = 0; j < half; j += V::W) {
+                const V u = V::gather(a + k + j, 1), v = V::gather(a + k + j + half, 1), w = V::gather(tw + j, 1);
+                vstore(a + k + j, cadd(u, v));
+                vstore(a + k + j + half, canon(mul(csub(u, v), w)));
+            }
+    }
     // test hook (tests/test_oracle_kat.py): the lane arithmetic on arbitrary 64-bit words, canonicalised --
     // out[0] = a b, out[1] = a^2, out[2] = a b + c, out[3] = a b + b c + c a (wide accumulator), out[4] = a^7, out[5] = a + (c mod p)
     static inline void test_arith(const u64* a, const u64* b, const u64* c, u64* out) {

@@ -152,7 +152,7 @@ static inline void commit_from_coeffs(const OCircuit& C, Batch& b, int oracle_in
         // transposed in blocks of rows so that every cache line of the row-major table is written once
         std::vector<u64> by_col(cols * N);
         const std::vector<u64> shift_pows = powers_of(GENERATOR, n);
-        forward_twiddles(C.lde_bits);
+        forward_stage_twiddles(C.lde_bits);
 #pragma omp parallel for schedule(dynamic, 1)
         for (size_t c = 0; c < cols; c++) coset_fft_bitrev_out(b.coeffs[c], shift_pows, C.lde_bits, &by_col[c * N]);
         const size_t RB = 64;
@@ -433,7 +433,10 @@ struct Challenges {
 static inline void eval_vanishing(const OCircuit& C, const Challenges& ch, u64 x, u64 l0_x, const PointVars& v, u64* out) {
     const size_t R = C.cfg.num_routed_wires, NC = C.cfg.num_challenges, npp = C.num_pp(), qdf = C.cfg.quotient_degree_factor;
     const size_t nsel = C.nsel(), nls = C.num_lookup_selectors, nlp = C.num_lookup_polys(), nsldc = C.num_sldc();
-    std::vector<u64> z1, ppt, lkt, gate(C.num_gate_constraints, 0);
+    // per-thread scratch, reused from point to point (this function runs 2^17 times per proof)
+    static thread_local std::vector<u64> z1, ppt, lkt, gate, terms;
+    z1.clear(), ppt.clear(), lkt.clear(), terms.clear();
+    gate.assign(C.num_gate_constraints, 0);
     for (size_t i = 0; i < NC; i++) {
         u64 z_x = v.zs[i], z_gx = v.zs_next[i];
         z1.push_back(fmul(l0_x, fsub(z_x, 1)));
@@ -523,7 +526,6 @@ static inline void eval_vanishing(const OCircuit& C, const Challenges& ch, u64 x
             for (int k = 0; k < 4; k++) gate[k] = fadd(gate[k], fmul(filter, v.wires[k]));  // public_inputs_hash = 0
         }
     }
-    std::vector<u64> terms;
     terms.insert(terms.end(), z1.begin(), z1.end());
     terms.insert(terms.end(), ppt.begin(), ppt.end());
     terms.insert(terms.end(), lkt.begin(), lkt.end());

@@ -10,6 +10,7 @@ struct V256 {
     __m256i v;
     static inline V256 set1(u64 x) { return V256{_mm256_set1_epi64x((long long)x)}; }
     static inline V256 gather(const u64* base, size_t stride) {
+        if (stride == 1) return V256{_mm256_loadu_si256((const __m256i*)base)};
         const long long s = (long long)stride;
         return V256{_mm256_i64gather_epi64((const long long*)base, _mm256_set_epi64x(3 * s, 2 * s, s, 0), 8)};
     }
@@ -35,4 +36,5 @@ void simd256_hash_rows(const SparsePoseidon* S, const u64* rows, size_t row_stri
 }
 void simd256_compress_pairs(const SparsePoseidon* S, const Digest* src, Digest* dst) { PoseidonLanes<V256>::compress_pairs(*S, src, dst); }
 void simd256_test_arith(const u64* a, const u64* b, const u64* c, u64* out) { PoseidonLanes<V256>::test_arith(a, b, c, out); }
+void simd256_dif_stage(u64* a, size_t n, size_t half, const u64* tw) { PoseidonLanes<V256>::dif_stage(a, n, half, tw); }
 }  // namespace orc

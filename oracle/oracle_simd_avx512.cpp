@@ -10,6 +10,7 @@ struct V512 {
     __m512i v;
     static inline V512 set1(u64 x) { return V512{_mm512_set1_epi64((long long)x)}; }
     static inline V512 gather(const u64* base, size_t stride) {
+        if (stride == 1) return V512{_mm512_loadu_si512((const void*)base)};
         const __m512i idx = _mm512_mullo_epi64(_mm512_set_epi64(7, 6, 5, 4, 3, 2, 1, 0), _mm512_set1_epi64((long long)stride));
         return V512{_mm512_i64gather_epi64(idx, base, 8)};
     }
@@ -30,4 +31,5 @@ void simd512_hash_rows(const SparsePoseidon* S, const u64* rows, size_t row_stri
 }
 void simd512_compress_pairs(const SparsePoseidon* S, const Digest* src, Digest* dst) { PoseidonLanes<V512>::compress_pairs(*S, src, dst); }
 void simd512_test_arith(const u64* a, const u64* b, const u64* c, u64* out) { PoseidonLanes<V512>::test_arith(a, b, c, out); }
+void simd512_dif_stage(u64* a, size_t n, size_t half, const u64* tw) { PoseidonLanes<V512>::dif_stage(a, n, half, tw); }
 }  // namespace orc

@@ -38,6 +38,7 @@ def lib():
         L.orc_hash_no_pad.argtypes = [u64p, sz, u64p]
         L.orc_two_to_one.argtypes = [u64p, u64p, u64p]
         L.orc_fft.argtypes = [u64p, C.c_int, C.c_int]
+        L.orc_fft_bitrev_out.argtypes = [u64p, C.c_int]
         L.orc_lde.argtypes = [u64p, C.c_int, C.c_int, u64p]
         L.orc_merkle_cap.restype, L.orc_merkle_cap.argtypes = sz, [u64p, sz, sz, C.c_int, u64p]
         L.orc_gf_2_8_mul.restype, L.orc_gf_2_8_mul.argtypes = C.c_uint8, [C.c_uint8, C.c_uint8]

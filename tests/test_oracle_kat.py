@@ -114,6 +114,28 @@ def test_simd_hash_is_the_textbook_hash(orc, lanes):
         L.orc_set_simd_lanes(8)
 
 
+@pytest.mark.parametrize("lanes", [8, 4, 1])
+def test_bit_reversed_output_transform_is_the_textbook_transform(orc, lanes):
+    """fft_bitrev_out (the commitments' transform: decimation in frequency, no permutation pass, SIMD butterflies under the fast
+    switch) leaves X[k] of the textbook fft_inplace at position rev(k) -- sizes 2^0 .. 2^12, extreme and random words."""
+    L, r = orc.lib(), random.Random(17 + lanes)
+    try:
+        for fast in (0, 1):
+            L.orc_set_fast_hash(fast)
+            L.orc_set_simd_lanes(lanes)
+            for bits in list(range(0, 9)) + [12]:
+                n = 1 << bits
+                v = [r.choice([0, 1, P - 1, P - 2, 0xFFFFFFFF, 1 << 32]) if r.random() < 0.2 else r.randrange(P) for _ in range(n)]
+                a, b = (C.c_uint64 * n)(*v), (C.c_uint64 * n)(*v)
+                L.orc_fft(a, bits, 0)
+                L.orc_fft_bitrev_out(b, bits)
+                rev = [int(format(i, "0%db" % bits)[::-1], 2) if bits else 0 for i in range(n)]
+                assert [b[rev[k]] for k in range(n)] == list(a), (fast, bits)
+    finally:
+        L.orc_set_fast_hash(0)
+        L.orc_set_simd_lanes(8)
+
+
 def test_batch_inverse_is_elementwise_inverse(orc):
     """One inversion per block (the permutation and lookup stages of the oracle): equal to finv element by element, zeros stay
     zero (finv(0) = 0), block boundaries (1024) and sizes 0, 1 covered."""
