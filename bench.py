@@ -373,9 +373,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU baseline is reported at N = 1 only
         import oracle_lib  # the checker, used here only as the reported CPU baseline
         oc = oracle_lib.OracleCircuit(data.blob)
-        # The port stops scaling at 16-32 threads on the 2 x 64-core EPYC 9575F host of the GPU boxes: one proof takes 1.09 s on
-        # 128 threads, 0.62 s on 64, 0.44 s on 32 and on 16, 0.68 s on 8, 4.1 s on one (tools/orc_scale.py fast,
-        # profiles/r03_cpu_baseline_scaling.log).  Use the best: 32, or the container's CPU quota when that is lower.
+        # A one-GPU box gives its container 16 of the host's 2 x 64 EPYC 9575F cores (cgroup cpu.max), and that is where the port
+        # stops scaling: one proof takes 0.41 s on 16 threads, 0.44 s on 32, 0.63 s on 64 or 8, 1.0 s on 128, 3.5 s on one
+        # (tools/orc_scale.py fast, profiles/r03_cpu_baseline_scaling.log).  Threads = the quota, at most --cpu-threads.
         all_cores = oracle_lib.lib().orc_num_threads()
         quota = cpu_quota_cores()  # the GPU boxes hand a container a share of the host's cores: threads beyond it only add switches
         cores = max(1, min(all_cores, args.cpu_threads, int(quota + 0.999) if quota else all_cores))
