@@ -345,6 +345,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 // help, vmcnt retires in order.)  Natural-order input and bit-reversed output only (the LDE), which is where the time is.
 // block id -> work id such that the work ids handled by one XCD (block ids congruent mod 8) are consecutive
 __device__ __forceinline__ u32 xcd_swizzle(u32 b, u32 grid) { return (grid & 7) ? b : (b & 7) * (grid >> 3) + (b >> 3); }
+// every global load written above this line is issued before any instruction below it (the loads themselves complete in
+// order; their consumers wait with s_waitcnt vmcnt(n) as usual)
+__device__ __forceinline__ void loads_issued() { asm volatile("" ::: "memory"); }
 template <bool SPLIT>
 __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
     extern __shared__ __align__(16) u64 lds[];
@@ -364,6 +367,8 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
     const u64* pre = a.pre ? a.pre + (size_t)coset * full : nullptr;
     const u64* post = a.post ? a.post + (size_t)coset * full : nullptr;
     u64 x[16];
+    u64 w[15];
+    bool tw_in_flight = false;  // SPLIT with the folded table: the first step's twiddles are fetched behind the load stage
     if (SPLIT) {
         // stage h = n_full / 2 on the fly: sums feed the first half of the (bit-reversed) output, differences the second
         if (pre) {
@@ -371,16 +376,46 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
             // point (s^i, or s^i w^i for the differences) and two multiplications instead of four loads and up to three
             const u64 S = pre[n];
             const u64* scale = half ? (a.pre_tw ? a.pre_tw + (size_t)coset * n : nullptr) : pre;
+            if (!half || scale) {
+                // All 48 loads of the thread are ISSUED before the first product (loads_issued): left to itself the compiler
+                // keeps the register count down by loading one or two points, waiting, multiplying, loading the next --
+                // sixteen dependent L2 round trips per wave, which is what the kernel spent its time on (rocprofv3: waves
+                // parked 58 % of their life, VALU at 63 % of what the hash kernels reach; profiles/r03_sq_wait_counters.txt).
+                // The second half of the scale values is fetched behind the first four points: all 48 at once need more
+                // than the 128 registers of a four-wave kernel.
+                u64 uu[16], vv[16], sc[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const u32 i = t + T * k;
-                const u64 u = in[i], v = gl::mul_nb(in[i + n], S);
-                if (!half)
-                    x[k] = gl::mul_nb(gl::add(u, v), scale[i]);
-                else if (scale)
-                    x[k] = gl::mul_nb(gl::sub(u, v), scale[i]);
-                else
+                for (int k = 0; k < 16; k++) uu[k] = in[t + T * k];
+#pragma unroll
+                for (int k = 0; k < 16; k++) vv[k] = in[t + T * k + n];
+#pragma unroll
+                for (int k = 0; k < 8; k++) sc[k] = scale[t + T * k];
+                loads_issued();
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (k == 4) {
+                        loads_issued();
+#pragma unroll
+                        for (int j = 8; j < 16; j++) sc[j] = scale[t + T * j];
+                        loads_issued();
+                    }
+                    if (k == 12) {  // three quarters of the point registers are free again: the first step's twiddles
+                        loads_issued();
+                        ntt_r16_load_tw(w, a.tw, t, logn - 4, a.log_nmax, 4);
+                        loads_issued();
+                    }
+                    const u64 v = gl::mul_nb(vv[k], S);
+                    x[k] = gl::mul_nb(half ? gl::sub(uu[k], v) : gl::add(uu[k], v), sc[k]);
+                }
+                tw_in_flight = true;
+            } else {
+                // no folded table (the small transforms of the later FRI rounds): scale and first-stage twiddle separately
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const u32 i = t + T * k;
+                    const u64 u = in[i], v = gl::mul_nb(in[i + n], S);
                     x[k] = gl::mul_nb(gl::mul_nb(gl::sub(u, v), pre[i]), a.tw[(size_t)i << (a.log_nmax - a.logn)]);
+                }
             }
         } else {
 #pragma unroll
@@ -406,14 +441,30 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
             for (int k = 0; k < 16; k++) x[k] = w0.at(lds, k);
         }
     } else {
+        // points, scales and the first step's twiddles: all issued before the first product (loads_issued)
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = in[t + T * k];
+        const int rem0 = (logn & 3) ? (logn & 3) : 4;
         if (pre) {
+            u64 pv[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = gl::mul_nb(x[k], pre[t + T * k]);
+            for (int k = 0; k < 16; k++) pv[k] = pre[t + T * k];
+            loads_issued();
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k == 8) {
+                    loads_issued();
+                    ntt_r16_load_tw(w, a.tw, t, logn - 4, a.log_nmax, rem0);
+                    loads_issued();
+                }
+                x[k] = gl::mul_nb(x[k], pv[k]);
+            }
+        } else {
+            ntt_r16_load_tw(w, a.tw, t, logn - 4, a.log_nmax, rem0);
+            loads_issued();
         }
+        tw_in_flight = true;
     }
-    u64 w[15];
     if (SPLIT) {
         // Four stages straight from the load layout (stride T: h = n/2 .. n/16), ONE exchange across the workgroup, and from
         // there on 2^(logn-4)-point transforms that each live inside one wave's 1024 points (thread t works on block
@@ -421,7 +472,7 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
         // later exchange is between the lanes of a wave and costs no barrier, and the waves of a workgroup drift apart so
         // that one's LDS and memory waits overlap another's butterflies.  (Round 2 first ran all four exchanges through
         // __syncthreads: the waves were parked 55 % of the time.)
-        ntt_r16_load_tw(w, a.tw, t, logn - 4, a.log_nmax, 4);
+        if (!tw_in_flight) ntt_r16_load_tw(w, a.tw, t, logn - 4, a.log_nmax, 4);
         ntt_r16_stage<0>(x, w);
         ntt_r16_stage<1>(x, w);
         ntt_r16_stage<2>(x, w);
@@ -496,7 +547,7 @@ __global__ __launch_bounds__(1024) void k_ntt_r16(NttArgs a) {
     // first step: the leading rem = logn mod 4 (or 4) stages on the whole array, stride M = n / 16
     // (with M = n / 16 stage A has h = n / 2^(A+1): these ARE the first `rem` stages of the whole transform)
     const int rem = (logn & 3) ? (logn & 3) : 4;
-    ntt_r16_load_tw(w, a.tw, t, logn - 4, a.log_nmax, rem);
+    if (!tw_in_flight) ntt_r16_load_tw(w, a.tw, t, logn - 4, a.log_nmax, rem);
     ntt_r16_stage<0>(x, w);
     if (rem >= 2) ntt_r16_stage<1>(x, w);
     if (rem >= 3) ntt_r16_stage<2>(x, w);
@@ -645,18 +696,37 @@ __global__ __launch_bounds__(256, MINW) void k_ntt_pass1_r16(Pass1Args a) {
     const u64* pre = a.pre ? a.pre + (size_t)coset * n : nullptr;
     const u32 j2_0 = tile << a.log_T;
     u64 x[16], w[15];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const u32 e = t + 256 * k;
-        const u32 idx = (e >> a.log_T) * n2 + j2_0 + (e & (T - 1));  // < n <= 2^22
-        x[k] = in[idx];
-        // (the coset scale s^idx as s^(row n2) s^j2 from the hot corner of the table -- two multiplies instead of an 8 n-byte
-        // stream per (column, coset) -- was measured at n = 2^19 and is slower, 67.3 vs 61.7 ms per 16 proofs: the kernel is
-        // VALU bound, not waiting on these streams; likewise the output twiddle below)
-        if (pre) x[k] = gl::mul_nb(x[k], pre[idx]);
-    }
     const int rem = (a.log_n1 & 3) ? (a.log_n1 & 3) : 4;
-    ntt_p1_load_tw(w, a.tw, t, 8, a.log_T, a.logn, rem);
+    // every load of the first step -- 16 points, their coset scales, the twiddles -- is issued before the first product
+    // (loads_issued, see k_ntt_r16: the compiler otherwise loads a point, waits, multiplies, loads the next)
+    // (the coset scale s^idx as s^(row n2) s^j2 from the hot corner of the table -- two multiplies instead of an 8 n-byte
+    // stream per (column, coset) -- was measured at n = 2^19 and is slower, 67.3 vs 61.7 ms per 16 proofs; likewise the
+    // output twiddle below)
+    // element e = t + 256 k of the tile sits at index (e >> log_T) n2 + j2_0 + (e & (T - 1)) of the column; with t < 256 that is
+    // at(t) + step(k), a per-thread part and a UNIFORM part (T <= 256: the row advances by 256 / T per k; T > 256: 256 k splits
+    // into row and column without a carry from t), so the sixteen addresses cost one vector offset and scalar arithmetic
+    const u32 at = (t >> a.log_T) * n2 + j2_0 + (t & (T - 1));  // index < n <= 2^22
+    auto step = [&](int k) -> u32 { return ((256u * (u32)k) >> a.log_T) * n2 + ((256u * (u32)k) & (T - 1)); };
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = in[at + step(k)];
+    if (pre) {
+        u64 pv[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) pv[k] = pre[at + step(k)];
+        loads_issued();
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (k == 8) {  // half of the scale registers are free again
+                loads_issued();
+                ntt_p1_load_tw(w, a.tw, t, 8, a.log_T, a.logn, rem);
+                loads_issued();
+            }
+            x[k] = gl::mul_nb(x[k], pv[k]);
+        }
+    } else {
+        ntt_p1_load_tw(w, a.tw, t, 8, a.log_T, a.logn, rem);
+        loads_issued();
+    }
     ntt_r16_stage<0>(x, w);
     if (rem >= 2) ntt_r16_stage<1>(x, w);
     if (rem >= 3) ntt_r16_stage<2>(x, w);
@@ -682,14 +752,15 @@ __global__ __launch_bounds__(256, MINW) void k_ntt_pass1_r16(Pass1Args a) {
     }
 #pragma unroll
     for (int r = 0; r < 16; r++) lds[ntt_pad(base_idx + (u32)r * stride)] = x[r];
+    // the output twiddles are fetched across the barrier (x is dead: the registers are free)
+    u64 ot[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) ot[k] = a.out_tw[at + step(k)];
+    loads_issued();
     __syncthreads();
     const NttLdsWalk fin(t, 256);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const u32 e = t + 256 * k;
-        const u32 o = (e >> a.log_T) * n2 + j2_0 + (e & (T - 1));
-        out[o] = gl::mul_nb(fin.at(lds, k), a.out_tw[o]);
-    }
+    for (int k = 0; k < 16; k++) out[at + step(k)] = gl::mul_nb(fin.at(lds, k), ot[k]);
 }
 // out_tw[r * n2 + j2] = tw[rev(r) * j2]   (r < n1, j2 < n2; tw = w^i, i < n)
 __global__ void k_pass1_out_tw(const u64* __restrict__ tw, u64* __restrict__ out_tw, int logn, int log_n1) {

@@ -34,14 +34,15 @@ struct Stamp {
 #define REP4(X) X X X X X X X X X X X X X X X X  // 16 x 8 = 128 instructions per loop trip: the loop's own s_add / s_cmp / s_cbranch stay under 3 %
 enum Op {
     ADD_E32, ADD_E64, MOV, ADDCO_CHAIN, ADDCO_SPACED, MAD64, MAD64_CARRY, MUL_LO, MUL_HI, LSHL_ADD_U64, MAD_U32_U24, CNDMASK_VCC, ADD3, ALIGNBIT, SNOP0, SNOP1,
-    MIX_MAD_ADD, XOR3, CNDMASK_SGPR, CMP_CNDMASK, SUBB_CHAIN, MAD_EPS_INLINE, NUM_OPS
+    MIX_MAD_ADD, XOR3, CNDMASK_SGPR, CMP_CNDMASK, SUBB_CHAIN, MAD_EPS_INLINE, MAD_NOP0, MAD_NOP1, MAD_SALU, NUM_OPS
 };
 static const char* OP_NAME[NUM_OPS] = {"v_add_u32 (e32)", "v_add_u32 (e64, 2 SGPR-free)", "v_mov_b32", "v_add_co/v_addc_co back-to-back (vcc)",
                                        "v_add_co x4 then v_addc_co x4 (4 sgpr pairs)", "v_mad_u64_u32 (no carry use)", "v_mad_u64_u32 + v_addc_co on its carry (2 apart)",
                                        "v_mul_lo_u32", "v_mul_hi_u32", "v_lshl_add_u64", "v_mad_u32_u24", "v_cndmask_b32 (vcc)", "v_add3_u32", "v_alignbit_b32",
                                        "s_nop 0", "s_nop 1", "mad64 : add_e32 = 1 : 1 interleaved", "v_lshl_add_u32",
-                                       "v_cndmask_b32_e64 (sgpr pair written before the loop)", "v_cmp_lt_u32 x4 then v_cndmask x4 (4 sgpr pairs)", "v_sub_co x4 then v_subb_co x4 (4 sgpr pairs)", "v_mad_u64_u32 v, s, v, -1, v (inline constant)"};
-static const int OP_INSTR_PER_TRIP[NUM_OPS] = {128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
+                                       "v_cndmask_b32_e64 (sgpr pair written before the loop)", "v_cmp_lt_u32 x4 then v_cndmask x4 (4 sgpr pairs)", "v_sub_co x4 then v_subb_co x4 (4 sgpr pairs)", "v_mad_u64_u32 v, s, v, -1, v (inline constant)",
+                                       "v_mad_u64_u32 ; s_nop 0 alternating (per mad)", "v_mad_u64_u32 ; s_nop 1 alternating (per mad)", "v_mad_u64_u32 ; s_andn2_b64 alternating (per mad)"};
+static const int OP_INSTR_PER_TRIP[NUM_OPS] = {128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(Stamp* stamps, uint32_t* sink, uint32_t seed, int trips) {
@@ -140,6 +141,17 @@ __global__ __launch_bounds__(256) void k(Stamp* stamps, uint32_t* sink, uint32_t
             REP4(asm volatile("v_mad_u64_u32 %0, %8, %12, -1, %0\n v_mad_u64_u32 %1, %9, %12, -1, %1\n v_mad_u64_u32 %2, %10, %12, -1, %2\n v_mad_u64_u32 %3, %11, %12, -1, %3\n"
                               "v_mad_u64_u32 %4, %8, %12, -1, %4\n v_mad_u64_u32 %5, %9, %12, -1, %5\n v_mad_u64_u32 %6, %10, %12, -1, %6\n v_mad_u64_u32 %7, %11, %12, -1, %7"
                               : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7), "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "v"(m));)
+        } else if (OP == MAD_NOP0 || OP == MAD_NOP1 || OP == MAD_SALU) {
+            // does a wait-state filler (or a scalar op) between two vector ops cost vector issue slots when other waves are ready?
+#define MADX(F) "v_mad_u64_u32 %0, %8, %12, -1, %0\n" F "v_mad_u64_u32 %1, %9, %12, -1, %1\n" F "v_mad_u64_u32 %2, %10, %12, -1, %2\n" F "v_mad_u64_u32 %3, %11, %12, -1, %3\n" F \
+                "v_mad_u64_u32 %4, %8, %12, -1, %4\n" F "v_mad_u64_u32 %5, %9, %12, -1, %5\n" F "v_mad_u64_u32 %6, %10, %12, -1, %6\n" F "v_mad_u64_u32 %7, %11, %12, -1, %7\n" F
+            if (OP == MAD_NOP0) {
+                REP4(asm volatile(MADX("s_nop 0\n") : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7), "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "v"(m));)
+            } else if (OP == MAD_NOP1) {
+                REP4(asm volatile(MADX("s_nop 1\n") : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7), "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "v"(m));)
+            } else {
+                REP4(asm volatile(MADX("s_andn2_b64 %13, %13, %13\n") : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7), "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "v"(m), "s"(mask) : "scc");)
+            }
         }
     }
     uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
