@@ -1484,29 +1484,53 @@ __global__ __launch_bounds__(256) void k_perm_chunks(const u64* __restrict__ wir
 // time -- thread t takes row base + t, so every column read and write is coalesced -- with a workgroup scan per sweep
 // and the running total carried from sweep to sweep.  (A thread-owns-16-consecutive-rows split reads each 128-byte
 // line for 8 bytes: the PMC counters showed 32x the algorithmic traffic.)
+// Long columns (n > 2^14: few proofs fit a chunk, and one workgroup per (proof, challenge) walking 2^19 rows left the chip idle
+// for 5 ms per 16 proofs) are cut into `segs` = gridDim.z segments of equal length, a workgroup each: k_perm_seg_products first
+// multiplies every segment's quotients together, and a segment's sweep starts from the product of the segments before it.
+static const u32 PERM_MAX_SEGS = 64;
+__global__ __launch_bounds__(1024) void k_perm_seg_products(const u64* __restrict__ q, size_t q_batch_stride, u64* __restrict__ seg_tot, u32 n, u32 num_chunks) {
+    __shared__ u64 lds[1024];
+    const u32 ch = blockIdx.x, t = threadIdx.x, segs = gridDim.z, seg = blockIdx.z, seg_rows = n / segs;
+    const u64* qq = q + (size_t)blockIdx.y * q_batch_stride + (size_t)ch * num_chunks * n;
+    u64 prod = 1;
+    for (u32 r = seg * seg_rows + t; r < (seg + 1) * seg_rows; r += blockDim.x)
+        for (u32 c = 0; c < num_chunks; c++) prod = gl::mul(prod, qq[(size_t)c * n + r]);
+    lds[t] = prod;
+    __syncthreads();
+    for (u32 off = blockDim.x / 2; off > 0; off >>= 1) {
+        if (t < off) lds[t] = gl::mul(lds[t], lds[t + off]);
+        __syncthreads();
+    }
+    if (t == 0) seg_tot[((size_t)blockIdx.y * gridDim.x + ch) * segs + seg] = lds[0];
+}
 __global__ __launch_bounds__(1024) void k_perm_scan(const u64* __restrict__ q, size_t q_batch_stride, u64* __restrict__ zs, size_t zs_batch_stride, u32 n,
-                                                     u32 num_chunks, u32 num_challenges) {
+                                                     u32 num_chunks, u32 num_challenges, const u64* __restrict__ seg_tot /* null: one segment */) {
     __shared__ u64 lds[1024];
     __shared__ u64 s_carry;
-    const u32 ch = blockIdx.x, t = threadIdx.x;
+    const u32 ch = blockIdx.x, t = threadIdx.x, segs = gridDim.z, seg = blockIdx.z, seg_rows = n / segs;
     const u64* qq = q + (size_t)blockIdx.y * q_batch_stride + (size_t)ch * num_chunks * n;
     u64* z = zs + (size_t)blockIdx.y * zs_batch_stride + (size_t)ch * n;
     u64* pp = zs + (size_t)blockIdx.y * zs_batch_stride + ((size_t)num_challenges + (size_t)ch * (num_chunks - 1)) * n;
-    if (t == 0) s_carry = 1;
+    if (t == 0) {
+        u64 c0 = 1;
+        for (u32 s = 0; s < seg; s++) c0 = gl::mul(c0, seg_tot[((size_t)blockIdx.y * gridDim.x + ch) * segs + s]);
+        s_carry = c0;
+    }
     __syncthreads();
-    for (u32 base = 0; base < n; base += blockDim.x) {
+    for (u32 base = seg * seg_rows; base < (seg + 1) * seg_rows; base += blockDim.x) {
         const u32 r = base + t;
+        const bool live = r < (seg + 1) * seg_rows;
         u64 v[PERM_MAX_CHUNKS];
         u64 prod = 1;
 #pragma unroll
         for (u32 c = 0; c < PERM_MAX_CHUNKS; c++) {
-            v[c] = (c < num_chunks && r < n) ? qq[(size_t)c * n + r] : 1;
+            v[c] = (c < num_chunks && live) ? qq[(size_t)c * n + r] : 1;
             prod = gl::mul(prod, v[c]);
         }
         const u64 carry = s_carry;
         (void)block_scan_inclusive<true>(prod, lds);  // ends on a barrier: lds[] holds the inclusive products
         u64 acc = gl::mul(carry, t == 0 ? 1 : lds[t - 1]);
-        if (r < n) {
+        if (live) {
             z[r] = acc;
 #pragma unroll
             for (u32 c = 0; c < PERM_MAX_CHUNKS; c++) {

@@ -405,12 +405,45 @@ __global__ __launch_bounds__(256) void k_fri_compose(const PolyRef* __restrict__
 }
 // Division of both compositions by (X - z_b), combination final = Q_0 * alpha^{n1} + Q_1.
 //   Q[k-1] = sum_{i >= k} comp[i] z^(i-k) = z^-k * sum_{i>=k} comp[i] z^i         (remainder dropped, Q[n-1] = 0)
-// One workgroup per proof; extension-field suffix scan over n coefficients.
+// A workgroup per (proof, segment of the coefficients); extension-field suffix scan.  Short polynomials are one segment; long ones
+// (n > 2^14, where a chunk holds few proofs) are cut into gridDim.y segments counted from the TOP coefficient down, whose sums
+// k_fri_seg_sums forms first: a segment's sweep starts from the sum of the segments above it.
+static const u32 FRI_MAX_SEGS = 64;
+__global__ __launch_bounds__(1024) void k_fri_seg_sums(const u64* comp, size_t comp_batch_stride, const u64* pows, size_t pows_batch_stride, u32 n,
+                                                        u64* seg_sum /*[proof][2][segs][2]*/) {
+    __shared__ u64 la[1024], lb[1024];
+    const u32 t = threadIdx.x, segs = gridDim.y, seg = blockIdx.y, seg_len = n / segs;
+    for (u32 b = 0; b < 2; b++) {
+        const u64* c = comp + (size_t)blockIdx.x * comp_batch_stride + (size_t)(2 * b) * n;
+        const u64* zp = pows + (size_t)blockIdx.x * pows_batch_stride + (size_t)b * 2 * n;
+        E2 acc = gl::e2(0, 0);
+        for (u32 d = seg * seg_len + t; d < (seg + 1) * seg_len; d += blockDim.x) {
+            const u32 i = n - 1 - d;
+            acc = gl::add(acc, gl::mul(gl::e2(c[i], c[n + i]), gl::e2(zp[i], zp[n + i])));
+        }
+        __syncthreads();
+        la[t] = acc.a;
+        lb[t] = acc.b;
+        __syncthreads();
+        for (u32 off = blockDim.x / 2; off > 0; off >>= 1) {
+            if (t < off) {
+                la[t] = gl::add(la[t], la[t + off]);
+                lb[t] = gl::add(lb[t], lb[t + off]);
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            u64* o = seg_sum + (((size_t)blockIdx.x * 2 + b) * segs + seg) * 2;
+            o[0] = la[0];
+            o[1] = lb[0];
+        }
+    }
+}
 __global__ __launch_bounds__(1024) void k_fri_divide(const u64* comp, size_t comp_batch_stride, const u64* pows, size_t pows_batch_stride, const u64* chal,
-                                                      u32 n, u32 n1, u64* final_poly /*[2][n]*/, size_t final_batch_stride) {
+                                                      u32 n, u32 n1, u64* final_poly /*[2][n]*/, size_t final_batch_stride, const u64* seg_sum /* null: one segment */) {
     __shared__ u64 la[1024], lb[1024];
     __shared__ u64 s_carry[2];
-    const u32 t = threadIdx.x;
+    const u32 t = threadIdx.x, segs = gridDim.y, seg = blockIdx.y, seg_len = n / segs;
     const u64* cw = chal + (size_t)blockIdx.x * CH_WORDS;
     const E2 alpha = gl::e2(cw[CH_FRI_ALPHA], cw[CH_FRI_ALPHA + 1]);
     const E2 shift = gl::pow(alpha, n1);
@@ -422,11 +455,20 @@ __global__ __launch_bounds__(1024) void k_fri_divide(const u64* comp, size_t com
         const u64* c = comp + (size_t)blockIdx.x * comp_batch_stride + (size_t)(2 * b) * n;
         const u64* zp = pows + (size_t)blockIdx.x * pows_batch_stride + (size_t)b * 2 * n;         // z^i
         const u64* zi = pows + (size_t)blockIdx.x * pows_batch_stride + (size_t)(2 + b) * 2 * n;   // z^-i
-        if (t == 0) s_carry[0] = s_carry[1] = 0;
+        __syncthreads();  // the previous pass is done with s_carry
+        if (t == 0) {
+            E2 c0 = gl::e2(0, 0);
+            for (u32 s_ = 0; s_ < seg; s_++) {
+                const u64* o = seg_sum + (((size_t)blockIdx.x * 2 + b) * segs + s_) * 2;
+                c0 = gl::add(c0, gl::e2(o[0], o[1]));
+            }
+            s_carry[0] = c0.a;
+            s_carry[1] = c0.b;
+        }
         __syncthreads();
-        for (u32 base = 0; base < n; base += blockDim.x) {
+        for (u32 base = seg * seg_len; base < (seg + 1) * seg_len; base += blockDim.x) {
             const u32 d = base + t;
-            const bool live = d < n;
+            const bool live = d < (seg + 1) * seg_len;
             const u32 i = live ? n - 1 - d : 0;
             E2 term = gl::e2(0, 0);
             if (live) term = gl::mul(gl::e2(c[i], c[n + i]), gl::e2(zp[i], zp[n + i]));

@@ -46,7 +46,7 @@ struct Workspace {
     int* d_status = nullptr;
     u64* d_advice = nullptr;
     u64 *d_wires = nullptr, *d_wcoef = nullptr, *d_wlde = nullptr;
-    u64 *d_zs = nullptr, *d_zcoef = nullptr, *d_zlde = nullptr, *d_permq = nullptr, *d_lktmp = nullptr;
+    u64 *d_zs = nullptr, *d_zcoef = nullptr, *d_zlde = nullptr, *d_permq = nullptr, *d_perm_seg = nullptr, *d_fri_seg = nullptr, *d_lktmp = nullptr;
     u64 *d_qvals = nullptr, *d_qres = nullptr, *d_qcoef = nullptr, *d_qlde = nullptr;
     Tree wtree, ztree, qtree;
     ChalState* d_chal_state = nullptr;
@@ -609,6 +609,8 @@ static int build_workspace(p2_circuit* C, Workspace* W, size_t chunk, u32 ws_inp
     WS_ALLOC(W->d_zcoef, chunk * zc * n);
     WS_ALLOC(W->d_zlde, chunk * (zc + c.salt()) * N);
     WS_ALLOC(W->d_permq, chunk * NC * (c.num_partial_products() + 1) * n);
+    WS_ALLOC(W->d_perm_seg, chunk * NC * PERM_MAX_SEGS);
+    WS_ALLOC(W->d_fri_seg, chunk * 4 * FRI_MAX_SEGS);
     WS_ALLOC(W->d_lktmp, chunk * NC * (c.num_sldc_polys() + 1) * n);
     WS_ALLOC(W->d_qvals, chunk * NC * N);
     WS_ALLOC(W->d_qres, chunk * NC * N);
@@ -768,7 +770,14 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
     HIPCHECK(hipMemsetAsync(C->cur->d_zs, 0, (size_t)B * zs_s * 8, st));
     LAUNCH(C, "perm_chunks", k_perm_chunks, g1(n, 256, B), dim3(256), 0, C->cur->d_wires, ws, C->d_sigmas, C->d_k_is, C->d_subgroup, C->cur->d_chal,
            C->cur->d_permq, (size_t)NC * (npp + 1) * n, (u32)n, R, c.cfg.quotient_degree_factor, npp + 1, NC);
-    LAUNCH(C, "perm_scan", k_perm_scan, dim3(NC, B), dim3(1024), 0, C->cur->d_permq, (size_t)NC * (npp + 1) * n, C->cur->d_zs, zs_s, (u32)n, npp + 1, NC);
+    {
+        // columns longer than 2^14 rows in segments of 2^14 (at most PERM_MAX_SEGS), a workgroup per segment
+        const u32 segs = (u32)std::min<size_t>(std::max<size_t>(n >> 14, 1), PERM_MAX_SEGS);
+        if (segs > 1)
+            LAUNCH(C, "perm_scan", k_perm_seg_products, dim3(NC, B, segs), dim3(1024), 0, C->cur->d_permq, (size_t)NC * (npp + 1) * n, C->cur->d_perm_seg, (u32)n, npp + 1);
+        LAUNCH(C, "perm_scan", k_perm_scan, dim3(NC, B, segs), dim3(1024), 0, C->cur->d_permq, (size_t)NC * (npp + 1) * n, C->cur->d_zs, zs_s, (u32)n, npp + 1, NC,
+               segs > 1 ? C->cur->d_perm_seg : nullptr);
+    }
     // 5. lookup polynomials
     if (nlp) {
         LookupArgs a{};
@@ -896,8 +905,13 @@ static int prove_chunk(p2_circuit* C, u32 B, u32 n_inputs, const u64* d_values, 
     if (challenger(C, 3, C->cur->d_obs, (size_t)2 * C->n_obs, 2 * C->n_obs, 0, 0, B)) return P2_ERR_HIP;
     // 9. FRI: compose, divide, commit phase
     LAUNCH(C, "fri_compose", k_fri_compose, g1(n, 256, B), dim3(256), 0, C->cur->d_polyrefs, C->n_b0, C->n_b1, C->cur->d_chal, (u32)n, C->cur->d_comp, (size_t)4 * n);
-    LAUNCH(C, "fri_divide", k_fri_divide, dim3(B), dim3(1024), 0, C->cur->d_comp, (size_t)4 * n, C->cur->d_pows, (size_t)8 * n, C->cur->d_chal, (u32)n, C->n_b1, C->cur->d_fri_coef[0],
-           (size_t)2 * n);
+    {
+        const u32 segs = (u32)std::min<size_t>(std::max<size_t>(n >> 14, 1), FRI_MAX_SEGS);  // as in the permutation scan
+        if (segs > 1)
+            LAUNCH(C, "fri_divide", k_fri_seg_sums, dim3(B, segs), dim3(1024), 0, C->cur->d_comp, (size_t)4 * n, C->cur->d_pows, (size_t)8 * n, (u32)n, C->cur->d_fri_seg);
+        LAUNCH(C, "fri_divide", k_fri_divide, dim3(B, segs), dim3(1024), 0, C->cur->d_comp, (size_t)4 * n, C->cur->d_pows, (size_t)8 * n, C->cur->d_chal, (u32)n, C->n_b1,
+               C->cur->d_fri_coef[0], (size_t)2 * n, segs > 1 ? C->cur->d_fri_seg : nullptr);
+    }
     {
         u32 logn_r = C->logn;
         for (u32 r = 0; r < C->arities.size(); r++) {
