@@ -314,7 +314,24 @@ __global__ __launch_bounds__(256) void k_eval_polys(const u64* __restrict__ coef
     const u64* c = coeffs + (size_t)blockIdx.y * coeffs_batch_stride + (size_t)blockIdx.x * n;
     const u64* pa = pw + (size_t)blockIdx.y * pw_batch_stride;
     u64 sa = 0, sb = 0;
-    for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+    u32 i = threadIdx.x;
+    // four rows per trip, their twelve loads issued before the first product (loads_issued, kernels.h)
+    for (; i + 3 * blockDim.x < n; i += 4 * blockDim.x) {
+        u64 v[4], wa[4], wb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[k] = c[i + k * blockDim.x];
+            wa[k] = pa[i + k * blockDim.x];
+            wb[k] = pa[n + i + k * blockDim.x];
+        }
+        loads_issued();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            sa = gl::add(sa, gl::mul(v[k], wa[k]));
+            sb = gl::add(sb, gl::mul(v[k], wb[k]));
+        }
+    }
+    for (; i < n; i += blockDim.x) {
         u64 v = c[i];
         sa = gl::add(sa, gl::mul(v, pa[i]));
         sb = gl::add(sb, gl::mul(v, pa[n + i]));
@@ -351,7 +368,24 @@ __global__ __launch_bounds__(256) void k_eval_polys_refs(const EvalRef* __restri
     const u64* c = r.base + (size_t)blockIdx.y * r.batch_stride + (size_t)r.col * n;
     const u64* pa = pows + (size_t)blockIdx.y * pw_batch_stride + (size_t)r.pw_k * 2 * n;
     u64 sa = 0, sb = 0;
-    for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+    u32 i = threadIdx.x;
+    // four rows per trip, their twelve loads issued before the first product (loads_issued, kernels.h)
+    for (; i + 3 * blockDim.x < n; i += 4 * blockDim.x) {
+        u64 v[4], wa[4], wb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[k] = c[i + k * blockDim.x];
+            wa[k] = pa[i + k * blockDim.x];
+            wb[k] = pa[n + i + k * blockDim.x];
+        }
+        loads_issued();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            sa = gl::add(sa, gl::mul(v[k], wa[k]));
+            sb = gl::add(sb, gl::mul(v[k], wb[k]));
+        }
+    }
+    for (; i < n; i += blockDim.x) {
         u64 v = c[i];
         sa = gl::add(sa, gl::mul(v, pa[i]));
         sb = gl::add(sb, gl::mul(v, pa[n + i]));
