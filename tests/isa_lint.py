@@ -253,3 +253,27 @@ def count_reads_at_minimum(asm_text):
                 for r in defs:
                     state[r] = 0
     return n
+
+
+def longest_load_batch(asm_text, fragment):
+    """Most global loads a function whose name contains `fragment` has in flight at one point, walking its code in layout order
+    (uniform branches between the loads of a step do not end a batch): loads are counted from one `s_waitcnt vmcnt(..)` to the
+    next (a wait with a non-zero count leaves that many of them outstanding).
+    Guards the kernels whose first step is written as 'every load issued, then the arithmetic' (loads_issued in kernels.h)
+    against a compiler that goes back to loading one value, waiting, multiplying, loading the next."""
+    best = 0
+    for name, blocks in parse_functions(asm_text).items():
+        if fragment not in name:
+            continue
+        outstanding = 0
+        for _, instrs, _, _ in blocks:
+            for _, mn, ops in instrs:
+                if mn.startswith("global_load") or mn.startswith("buffer_load"):
+                    outstanding += 1
+                    best = max(best, outstanding)
+                elif mn == "s_waitcnt":
+                    m = re.search(r"vmcnt\((\d+)\)", " ".join(ops))
+                    if m:
+                        outstanding = min(outstanding, int(m.group(1)))
+    return best
+

@@ -107,3 +107,20 @@ def test_emitted_isa_keeps_two_wait_states_between_valu_sgpr_write_and_read(devi
     assert sum(len(b[1]) for blocks in funcs.values() for b in blocks) > 100000  # the parser saw the code, not an empty file
     hazards = isa_lint.sgpr_hazards(asm)
     assert hazards == [], hazards[:20]
+
+
+def test_ntt_kernels_issue_the_loads_of_a_step_together(device_build):
+    """Round 3's largest NTT gain was an ORDER: the compiler had serialised the load stage of the LDE into sixteen dependent
+    round trips (load a point, wait, multiply, load the next).  loads_issued() pins all loads of a step in front of its first
+    product; this holds the emitted code to it -- 40 of the half-column kernel's 48 loads in one batch (the rest follow behind
+    the first points for the register budget), points + coset scales of the first pass of the large transform, the 16 points and
+    the twiddles of the whole-column kernel.  And the planted case: a load-wait-load-wait stream counts as batches of one."""
+    asm = device_build[1]
+    assert isa_lint.longest_load_batch(asm, "k_ntt_r16ILb1") >= 40
+    assert isa_lint.longest_load_batch(asm, "k_ntt_pass1_r16") >= 32
+    assert isa_lint.longest_load_batch(asm, "k_ntt_r16ILb0") >= 32
+    planted = "f:\n" + "".join("\tglobal_load_dwordx2 v[%d:%d], v[0:1], off\n\ts_waitcnt vmcnt(0)\n" % (2 * i + 2, 2 * i + 3) for i in range(8)) + "\ts_endpgm\n.Lfunc_end0:\n"
+    assert isa_lint.longest_load_batch(planted, "f") == 1
+    pipelined = "g:\n" + "".join("\tglobal_load_dwordx2 v[%d:%d], v[0:1], off\n" % (2 * i + 2, 2 * i + 3) for i in range(8)) + "\ts_waitcnt vmcnt(6)\n\ts_endpgm\n.Lfunc_end1:\n"
+    assert isa_lint.longest_load_batch(pipelined, "g") == 8
+
