@@ -678,8 +678,10 @@ __device__ __forceinline__ void ntt_p1_load_tw(u64* w, const u64* __restrict__ t
             if (j < half) w[base + j] = tw[(size_t)((tp + ((u32)j << m)) >> log_T) << (tw_log - q)];
     }
 }
-// MINW = waves per SIMD the register budget is cut for: 4 -> 128 VGPRs with 44 bytes of scratch per lane, 2 -> 170 VGPRs and none
-// (measured at n = 2^19: the scratch-free build at half the occupancy is 1.5 x slower, 100.8 vs 67.3 ms per 16 proofs)
+// MINW = waves per SIMD the register budget is cut for.  With the tile addresses written as per-thread + uniform parts the
+// kernel needs 122 VGPRs and no scratch at four waves; the two-wave build (P2AES_PASS1_WAVES=2) is kept as an A/B switch.
+// (Before that: 128 VGPRs with 44 bytes of scratch at four waves, 170 and none at two -- and the scratch-free build at half the
+// occupancy was 1.5 x slower, 100.8 vs 67.3 ms per 16 proofs at n = 2^19.)
 template <int MINW>
 __global__ __launch_bounds__(256, MINW) void k_ntt_pass1_r16(Pass1Args a) {
     extern __shared__ __align__(16) u64 lds[];
